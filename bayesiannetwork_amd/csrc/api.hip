@@ -1,0 +1,488 @@
+// C ABI of libbn_hip.so (declared in include/bn_hip.h): argument checking, device
+// memory ownership and kernel launches.  No torch types, no exceptions across the
+// boundary.
+#include "../../include/bn_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fast.h"
+#include "kernels_generic.h"
+#include "plan.h"
+
+struct bn_plan {
+  bn::Plan p;
+};
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define BN_HIP_CHECK(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t err__ = (expr);                                                               \
+    if (err__ != hipSuccess)                                                                 \
+      return fail(BN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));         \
+  } while (0)
+
+#define BN_LAUNCH_CHECK(what)                                                                \
+  do {                                                                                       \
+    hipError_t err__ = hipGetLastError();                                                    \
+    if (err__ != hipSuccess)                                                                 \
+      return fail(BN_ERR_HIP, std::string("launch of ") + what + ": " + hipGetErrorString(err__)); \
+  } while (0)
+
+template <typename U>
+int upload(const std::vector<U>& host, U** dev, int64_t& bytes) {
+  *dev = nullptr;
+  if (host.empty()) return BN_OK;
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(U)));
+  bytes += host.size() * sizeof(U);
+  BN_HIP_CHECK(hipMemcpy(*dev, host.data(), host.size() * sizeof(U), hipMemcpyHostToDevice));
+  return BN_OK;
+}
+
+bn::FactorDims make_dims(const std::vector<int32_t>& dims) {
+  bn::FactorDims fd{};
+  fd.arity = (int32_t)dims.size();
+  fd.total = 0;
+  fd.elems = 1;
+  for (int32_t j = 0; j < bn::kMaxArity; ++j) {
+    fd.d[j] = j < fd.arity ? dims[j] : 1;
+    fd.base[j] = fd.total;
+    if (j < fd.arity) {
+      fd.total += dims[j];
+      fd.elems *= dims[j];
+    }
+  }
+  return fd;
+}
+
+constexpr int64_t kLdsLimit = 158 * 1024;
+constexpr int32_t kLlBlocks = 1024;
+
+void release(bn::Plan& p) {
+  for (auto& g : p.vgroups) {
+    if (g.d_in) (void)hipFree(g.d_in);
+    if (g.d_out) (void)hipFree(g.d_out);
+    if (g.d_c) (void)hipFree(g.d_c);
+  }
+  for (auto& g : p.fgroups) {
+    if (g.d_in) (void)hipFree(g.d_in);
+    if (g.d_out) (void)hipFree(g.d_out);
+    if (g.d_cpt) (void)hipFree(g.d_cpt);
+  }
+  if (p.arena) (void)hipFree(p.arena);
+  if (p.cpts) (void)hipFree(p.cpts);
+  if (p.scratch) (void)hipFree(p.scratch);
+  if (p.d_evidence_ptrs) (void)hipFree(p.d_evidence_ptrs);
+  if (p.h_evidence_ptrs) (void)hipHostFree(p.h_evidence_ptrs);
+  if (p.d_obs_off) (void)hipFree(p.d_obs_off);
+  if (p.d_obs_states) (void)hipFree(p.d_obs_states);
+  if (p.d_fill_off) (void)hipFree(p.d_fill_off);
+  if (p.d_fill_states) (void)hipFree(p.d_fill_states);
+}
+
+int32_t em_chunks(const bn::Plan& p) {
+  // enough (node, chunk) work items to fill the chip, never more chunks than 64-sample slices
+  const int64_t slices = p.ntiles * (p.tile / 64);
+  int64_t want = (4096 + p.n_nodes - 1) / p.n_nodes;
+  want = std::max<int64_t>(1, std::min<int64_t>(want, 256));
+  return (int32_t)std::min<int64_t>(want, slices);
+}
+
+template <typename T>
+int reset_messages_t(bn::Plan& p, hipStream_t s) {
+  T* arena = static_cast<T*>(p.arena);
+  const int32_t arrays = (int32_t)p.fill_count;
+  if (arrays > 0) {
+    int64_t max_elems = (int64_t)p.fill_max_states * p.npad;
+    int32_t gx = (int32_t)std::min<int64_t>((max_elems + 255) / 256, 4096);
+    for (int32_t first = 0; first < arrays; first += 65535) {
+      int32_t cnt = std::min(arrays - first, 65535);
+      hipLaunchKernelGGL(bn::fill_uniform<T>, dim3(gx, cnt), dim3(256), 0, s, arena, p.d_fill_off + first,
+                         p.d_fill_states + first, p.npad);
+      BN_LAUNCH_CHECK("fill_uniform");
+    }
+  }
+  const int64_t c_elems = (int64_t)p.n_nodes * p.npad;
+  BN_HIP_CHECK(hipMemsetAsync(arena + p.c_base, 0, c_elems * sizeof(T), s));
+  return BN_OK;
+}
+
+template <typename T>
+int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
+  T* arena = static_cast<T*>(p.arena);
+  const T* cpts = static_cast<const T*>(p.cpts);
+  const int32_t subs = p.tile / 64;
+  for (int32_t it = 0; it < iterations; ++it) {
+    for (auto& g : p.vgroups) {
+      const int32_t K = (int32_t)g.nodes.size();
+      int rc = bn::launch_variable_fast<T>(p, g, arena, s);
+      if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised variable kernel failed");
+      if (rc == 0) {
+        const int64_t blocks = (int64_t)K * p.ntiles * subs;
+        const size_t lds = (size_t)g.num_states * 64 * 24;
+        if (lds > 48 * 1024)
+          BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::variable_pass_generic<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bn::variable_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, g.d_in,
+                           g.d_out, g.d_c, K, g.num_inputs, g.num_states, p.tile, p.ntiles);
+        BN_LAUNCH_CHECK("variable_pass_generic");
+      }
+    }
+    for (auto& g : p.fgroups) {
+      const int32_t K = (int32_t)g.nodes.size();
+      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, s);
+      if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
+      if (rc == 0) {
+        bn::FactorDims fd = make_dims(g.dims);
+        const int64_t blocks = (int64_t)K * p.ntiles * subs;
+        const size_t lds = (size_t)fd.total * 64 * (8 + sizeof(T));
+        if (lds > 48 * 1024)
+          BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::factor_pass_generic<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bn::factor_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, cpts,
+                           g.d_in, g.d_out, g.d_cpt, K, fd, p.tile, p.ntiles);
+        BN_LAUNCH_CHECK("factor_pass_generic");
+      }
+    }
+  }
+  return BN_OK;
+}
+
+template <typename T>
+int em_accumulate_t(bn::Plan& p, double* accum, hipStream_t s) {
+  const T* arena = static_cast<const T*>(p.arena);
+  const T* cpts = static_cast<const T*>(p.cpts);
+  const int32_t nchunks = em_chunks(p);
+  double* partial = p.scratch + kLlBlocks;
+  for (auto& g : p.fgroups) {
+    const int32_t K = (int32_t)g.nodes.size();
+    int rc = bn::launch_em_fast<T>(p, g, arena, nchunks, partial, s);
+    if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised EM kernel failed");
+    if (rc > 0) continue;
+    bn::FactorDims fd = make_dims(g.dims);
+    const size_t lds = (size_t)fd.total * 65 * sizeof(T);
+    if (lds > 48 * 1024)
+      BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::em_partial_generic<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t gx = (uint32_t)((fd.elems + 255) / 256);
+    for (int32_t first = 0; first < K; first += 65535) {
+      const int32_t cnt = std::min(K - first, 65535);
+      hipLaunchKernelGGL(bn::em_partial_generic<T>, dim3(gx, nchunks, cnt), dim3(256), lds, s, arena,
+                         g.d_in + (int64_t)first * fd.arity, fd, p.N, p.tile, p.ntiles, nchunks, partial,
+                         g.d_cpt + first);
+      BN_LAUNCH_CHECK("em_partial_generic");
+    }
+  }
+  hipLaunchKernelGGL(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
+                     cpts, p.cpt_total, nchunks, accum);
+  BN_LAUNCH_CHECK("em_finalize");
+  return BN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bn_abi_version(void) { return 1; }
+
+const char* bn_last_error(void) { return g_error.c_str(); }
+
+int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const int32_t* num_states,
+                   const int32_t* parent_offsets, const int32_t* parent_indices, const int32_t* child_offsets,
+                   const int32_t* child_indices, const int32_t* observed_nodes, int32_t num_observed,
+                   bn_plan** out_plan) {
+  if (!out_plan) return fail(BN_ERR_INVALID, "out_plan is null");
+  *out_plan = nullptr;
+  bn_plan* h = new (std::nothrow) bn_plan();
+  if (!h) return fail(BN_ERR_INVALID, "out of host memory");
+  bn::Plan& p = h->p;
+  std::string err = bn::compile_plan(p, dtype, num_observations, num_nodes, num_states, parent_offsets,
+                                     parent_indices, child_offsets, child_indices, observed_nodes, num_observed);
+  if (!err.empty()) {
+    delete h;
+    return fail(BN_ERR_INVALID, err);
+  }
+  // shapes the generic kernels can hold in LDS
+  for (auto& g : p.vgroups) {
+    if ((int64_t)g.num_states * 64 * 24 > kLdsLimit) {
+      delete h;
+      return fail(BN_ERR_INVALID, "a node has more states than the variable kernel supports");
+    }
+  }
+  for (auto& g : p.fgroups) {
+    int64_t total = 0;
+    for (int32_t d : g.dims) total += d;
+    if (total * 64 * (8 + (int64_t)p.elem_size) > kLdsLimit || total * 65 * (int64_t)p.elem_size > kLdsLimit) {
+      delete h;
+      return fail(BN_ERR_INVALID, "a family's cardinalities sum to more than the factor kernel supports");
+    }
+  }
+
+  auto bail = [&](int rc) {
+    release(p);
+    delete h;
+    return rc;
+  };
+#define BN_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != BN_OK) return bail(rc__); \
+  } while (0)
+#define BN_TRY_HIP(expr)                                                                  \
+  do {                                                                                    \
+    hipError_t err__ = (expr);                                                            \
+    if (err__ != hipSuccess)                                                              \
+      return bail(fail(BN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__))); \
+  } while (0)
+
+  BN_TRY_HIP(hipGetDevice(&p.device));
+  p.device_bytes = 0;
+  BN_TRY_HIP(hipMalloc(&p.arena, (size_t)p.arena_elems * p.elem_size));
+  p.device_bytes += p.arena_elems * (int64_t)p.elem_size;
+  BN_TRY_HIP(hipMalloc(&p.cpts, (size_t)p.cpt_total * p.elem_size));
+  p.device_bytes += p.cpt_total * (int64_t)p.elem_size;
+  p.scratch_elems = kLlBlocks + p.cpt_total * (int64_t)em_chunks(p) + bn::fast_scratch_elems(p);
+  BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.scratch), (size_t)p.scratch_elems * sizeof(double)));
+  p.device_bytes += p.scratch_elems * 8;
+
+  for (auto& g : p.vgroups) {
+    BN_TRY(upload(g.in_off, &g.d_in, p.device_bytes));
+    BN_TRY(upload(g.out_off, &g.d_out, p.device_bytes));
+    BN_TRY(upload(g.c_off, &g.d_c, p.device_bytes));
+  }
+  for (auto& g : p.fgroups) {
+    BN_TRY(upload(g.in_off, &g.d_in, p.device_bytes));
+    BN_TRY(upload(g.out_off, &g.d_out, p.device_bytes));
+    BN_TRY(upload(g.cpt_off, &g.d_cpt, p.device_bytes));
+  }
+  if (!p.observed.empty()) {
+    std::vector<int32_t> obs_states;
+    for (int32_t o : p.observed) obs_states.push_back(p.states[o]);
+    BN_TRY(upload(p.obs_off, &p.d_obs_off, p.device_bytes));
+    BN_TRY(upload(obs_states, &p.d_obs_states, p.device_bytes));
+    BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_evidence_ptrs), p.observed.size() * sizeof(void*)));
+    BN_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&p.h_evidence_ptrs), p.observed.size() * sizeof(void*),
+                             hipHostMallocDefault));
+  }
+  {
+    // every message array and observation array starts uniform
+    std::vector<int64_t> offs;
+    std::vector<int32_t> sts;
+    int32_t max_states = 1;
+    for (const auto& e : p.edges) {
+      offs.push_back(e.v2f);
+      sts.push_back(e.states);
+      offs.push_back(e.f2v);
+      sts.push_back(e.states);
+      max_states = std::max(max_states, e.states);
+    }
+    for (size_t i = 0; i < p.observed.size(); ++i) {
+      offs.push_back(p.obs_off[i]);
+      sts.push_back(p.states[p.observed[i]]);
+    }
+    p.fill_count = (int64_t)offs.size();
+    p.fill_max_states = max_states;
+    BN_TRY(upload(offs, &p.d_fill_off, p.device_bytes));
+    BN_TRY(upload(sts, &p.d_fill_states, p.device_bytes));
+  }
+  BN_TRY(bn::prepare_fast(p));
+  BN_TRY(p.dtype == BN_F32 ? reset_messages_t<float>(p, nullptr) : reset_messages_t<double>(p, nullptr));
+  BN_TRY_HIP(hipStreamSynchronize(nullptr));
+#undef BN_TRY
+#undef BN_TRY_HIP
+  *out_plan = h;
+  return BN_OK;
+}
+
+int bn_plan_destroy(bn_plan* plan) {
+  if (!plan) return BN_OK;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(plan->p.device);
+  bn::release_fast(plan->p);
+  release(plan->p);
+  (void)hipSetDevice(prev);
+  delete plan;
+  return BN_OK;
+}
+
+int bn_plan_topology(const bn_plan* plan, int32_t* is_tree, int32_t* factor_graph_diameter) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  if (is_tree) *is_tree = plan->p.is_tree ? 1 : 0;
+  if (factor_graph_diameter) *factor_graph_diameter = plan->p.diameter;
+  return BN_OK;
+}
+
+int64_t bn_plan_cpt_elements(const bn_plan* plan) { return plan ? plan->p.cpt_total : -1; }
+
+int64_t bn_plan_device_bytes(const bn_plan* plan) { return plan ? plan->p.device_bytes : -1; }
+
+int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
+  if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  BN_HIP_CHECK(hipMemcpyAsync(p.cpts, cpts_dev, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+  p.cpts_set = true;
+  return BN_OK;
+}
+
+int bn_reset_messages(bn_plan* plan, void* stream) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  bn::Plan& p = plan->p;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
+}
+
+int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stream) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  bn::Plan& p = plan->p;
+  if (p.observed.empty()) return BN_OK;
+  if (!evidence_dev) return fail(BN_ERR_INVALID, "evidence_dev is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t count = p.observed.size();
+  int32_t max_states = 1;
+  for (size_t i = 0; i < count; ++i) {
+    if (!evidence_dev[i]) return fail(BN_ERR_INVALID, "an evidence pointer is null");
+    max_states = std::max(max_states, p.states[p.observed[i]]);
+  }
+  // the pinned staging table is reused by every call: wait until the previous copy has left it
+  BN_HIP_CHECK(hipStreamSynchronize(s));
+  std::memcpy(p.h_evidence_ptrs, evidence_dev, count * sizeof(void*));
+  BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, p.h_evidence_ptrs, count * sizeof(void*), hipMemcpyHostToDevice, s));
+  const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
+  for (size_t first = 0; first < count; first += 65535) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
+    if (p.dtype == BN_F32) {
+      hipLaunchKernelGGL(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
+                         (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
+                         p.d_obs_states + first, p.N, p.tile, p.ntiles);
+    } else {
+      hipLaunchKernelGGL(bn::evidence_scatter<double>, dim3(gx, cnt), dim3(256), 0, s,
+                         static_cast<double*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first),
+                         p.d_obs_off + first, p.d_obs_states + first, p.N, p.tile, p.ntiles);
+    }
+    BN_LAUNCH_CHECK("evidence_scatter");
+  }
+  return BN_OK;
+}
+
+int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  if (num_iterations < 0) return fail(BN_ERR_INVALID, "num_iterations must be >= 0");
+  bn::Plan& p = plan->p;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, s) : iterate_t<double>(p, num_iterations, s);
+}
+
+int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t total = (int64_t)p.n_nodes * p.npad;
+  const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
+  if (p.dtype == BN_F32) {
+    hipLaunchKernelGGL(bn::ll_partial<float>, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const float*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  } else {
+    hipLaunchKernelGGL(bn::ll_partial<double>, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const double*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  }
+  BN_LAUNCH_CHECK("ll_partial");
+  const double scale = average ? 1.0 / (double)p.N : 1.0;
+  hipLaunchKernelGGL(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, scale, out_dev);
+  BN_LAUNCH_CHECK("sum_partials");
+  return BN_OK;
+}
+
+static int gather(bn::Plan& p, int64_t a_off, int64_t b_off, int32_t states, void* out_dev, hipStream_t s) {
+  const int64_t total = p.N * states;
+  const uint32_t blocks = (uint32_t)((total + 255) / 256);
+  if (p.dtype == BN_F32) {
+    hipLaunchKernelGGL(bn::gather_rows<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+                       a_off, b_off, static_cast<float*>(out_dev), p.N, states, p.tile);
+  } else {
+    hipLaunchKernelGGL(bn::gather_rows<double>, dim3(blocks), dim3(256), 0, s, static_cast<const double*>(p.arena),
+                       a_off, b_off, static_cast<double*>(out_dev), p.N, states, p.tile);
+  }
+  BN_LAUNCH_CHECK("gather_rows");
+  return BN_OK;
+}
+
+int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
+  return gather(p, p.c_off[node], -1, 1, out_dev, static_cast<hipStream_t>(stream));
+}
+
+int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
+  const bn::EdgeLayout& e = p.edges[node];
+  return gather(p, e.f2v, e.v2f, e.states, out_dev, static_cast<hipStream_t>(stream));
+}
+
+int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction, void* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (owner < 0 || owner >= p.n_nodes) return fail(BN_ERR_INVALID, "owner out of range");
+  if (slot == -2) {
+    if (p.observed_slot_of[owner] < 0) return fail(BN_ERR_INVALID, "node is not observed");
+    return gather(p, p.obs_off[p.observed_slot_of[owner]], -1, p.states[owner], out_dev,
+                  static_cast<hipStream_t>(stream));
+  }
+  if (slot < -1 || slot >= (int32_t)p.parents[owner].size()) return fail(BN_ERR_INVALID, "slot out of range");
+  if (direction != 0 && direction != 1) return fail(BN_ERR_INVALID, "direction must be 0 or 1");
+  const bn::EdgeLayout& e = slot < 0 ? p.edges[owner] : p.edges[p.parent_edge_base[owner] + slot];
+  return gather(p, direction == 0 ? e.v2f : e.f2v, -1, e.states, out_dev, static_cast<hipStream_t>(stream));
+}
+
+int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bn::FamilyArgs fa{};
+  fa.fd = make_dims(p.cpt_dims[node]);
+  for (size_t q = 0; q < p.parents[node].size(); ++q) fa.in_off[q] = p.edges[p.parent_edge_base[node] + q].v2f;
+  fa.in_off[p.parents[node].size()] = p.edges[node].v2f;
+  fa.cpt_off = p.cpt_off[node];
+  const int64_t total = p.N * fa.fd.elems;
+  const uint32_t blocks = (uint32_t)((total + 255) / 256);
+  if (p.dtype == BN_F32) {
+    hipLaunchKernelGGL(bn::family_marginal<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+                       static_cast<const float*>(p.cpts), fa, static_cast<float*>(out_dev), p.N, p.tile);
+  } else {
+    hipLaunchKernelGGL(bn::family_marginal<double>, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const double*>(p.arena), static_cast<const double*>(p.cpts), fa,
+                       static_cast<double*>(out_dev), p.N, p.tile);
+  }
+  BN_LAUNCH_CHECK("family_marginal");
+  return BN_OK;
+}
+
+int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream) {
+  if (!plan || !accum_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, s) : em_accumulate_t<double>(p, accum_dev, s);
+}
+
+}  // extern "C"

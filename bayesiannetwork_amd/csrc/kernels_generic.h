@@ -1,0 +1,445 @@
+// Shape-agnostic kernels: any fan-in, any cardinality up to kMaxStatesGeneric, any arity
+// up to kMaxArity.  One lane = one observation; a 64-lane workgroup handles one node and
+// one 64-observation slice of a tile, and keeps its per-lane vectors in LDS as
+// [index][lane] so that runtime-indexed accesses never leave the chip and never
+// bank-conflict (lane is the fastest axis).  The specialised kernels in kernels_fast.h
+// replace these for the shapes that matter for throughput; results are interchangeable.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace bn {
+
+template <typename T>
+__device__ __forceinline__ T dev_log(T x);
+template <>
+__device__ __forceinline__ float dev_log<float>(float x) {
+  return logf(x);
+}
+template <>
+__device__ __forceinline__ double dev_log<double>(double x) {
+  return log(x);
+}
+template <typename T>
+__device__ __forceinline__ T dev_exp(T x);
+template <>
+__device__ __forceinline__ float dev_exp<float>(float x) {
+  return expf(x);
+}
+template <>
+__device__ __forceinline__ double dev_exp<double>(double x) {
+  return exp(x);
+}
+
+// element address inside a message array
+__device__ __forceinline__ int64_t msg_index(int64_t base, int64_t tile_id, int32_t states, int32_t s,
+                                             int32_t tile, int32_t lane_in_tile) {
+  return base + (tile_id * states + s) * (int64_t)tile + lane_in_tile;
+}
+
+// ---------------------------------------------------------------------------------
+// Variable pass.  For one node and 64 observations, with in_i[s] the messages waiting at
+// the variable (VariableNodeGroup.calculate_outputs, spa_v3/factor_graph.py:112-144):
+//
+//   P[s]      = prod_i in_i[s]                                   (exp of the reference's x2)
+//   c         = log sum_s P[s]                                   (local log-likelihood, :133-144)
+//   to child factor i :  out_i[s] = (P[s]/in_i[s]) / sum_s' (P[s']/in_i[s'])     (:120,:127)
+//   to local factor   :  out[s]   = (P[s]/in_local[s]) / sum_s' P[s']            (:138)
+//
+// The reference evaluates these through log / sum / softmax / exp to survive underflow.
+// Here the product is carried as a double mantissa plus an integer exponent per state
+// (renormalised every four factors), which is the same quantity without any
+// transcendental and without the ~1e-7*|log| rounding that a float32 sum of several
+// hundred logs picks up.  An exactly-zero input gives P = 0 and 0/0 = NaN on its own
+// outgoing message and 0 on the others, as -inf - -inf does in the reference.
+//
+// grid.x = K * ntiles * (tile / 64), block = 64, dynamic LDS = S*64*24 bytes.
+constexpr int32_t kDeadExponent = -(1 << 28);
+
+__device__ __forceinline__ int32_t clamp_shift(int32_t e) { return e < -4000 ? -4000 : (e > 4000 ? 4000 : e); }
+
+template <typename T>
+__global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ arena,
+                                                           const int64_t* __restrict__ in_off,
+                                                           const int64_t* __restrict__ out_off,
+                                                           const int64_t* __restrict__ c_off, int32_t K,
+                                                           int32_t I, int32_t S, int32_t tile,
+                                                           int64_t ntiles) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double* mant = reinterpret_cast<double*>(lds_raw);                       // [S][64]
+  double* quo = mant + (size_t)S * 64;                                     // [S][64]
+  int32_t* expo = reinterpret_cast<int32_t*>(quo + (size_t)S * 64);        // [S][64]
+  int32_t* qexp = expo + (size_t)S * 64;                                   // [S][64]
+
+  const int32_t lane = threadIdx.x;
+  const int32_t subs = tile / 64;
+  int64_t w = blockIdx.x;
+  const int32_t sub = (int32_t)(w % subs);
+  w /= subs;
+  const int64_t t = w % ntiles;
+  const int32_t k = (int32_t)(w / ntiles);
+  if (k >= K) return;
+  const int32_t lt = sub * 64 + lane;
+
+  const int64_t* in_k = in_off + (int64_t)k * I;
+  const int64_t* out_k = out_off + (int64_t)k * I;
+
+  // P[s] as mantissa * 2^exponent
+  int32_t emax = kDeadExponent;
+  for (int32_t s = 0; s < S; ++s) {
+    double m = 1.0;
+    int32_t e = 0;
+    for (int32_t i = 0; i < I; ++i) {
+      m *= (double)arena[msg_index(in_k[i], t, S, s, tile, lt)];
+      if ((i & 3) == 3 || i == I - 1) {
+        int de = 0;
+        m = frexp(m, &de);
+        e += de;
+      }
+    }
+    if (m == 0.0) e = kDeadExponent;
+    mant[s * 64 + lane] = m;
+    expo[s * 64 + lane] = e;
+    emax = e > emax ? e : emax;
+  }
+  double z = 0.0;
+  for (int32_t s = 0; s < S; ++s) z += ldexp(mant[s * 64 + lane], clamp_shift(expo[s * 64 + lane] - emax));
+  arena[msg_index(c_off[k], t, 1, 0, tile, lt)] = (T)((double)emax * 0.6931471805599453 + log(z));
+
+  for (int32_t i = 0; i < I; ++i) {
+    const int64_t dst = out_k[i];
+    if (dst < 0) continue;
+    // leave-one-out quotient, again as mantissa * 2^exponent
+    int32_t xmax = kDeadExponent;
+    for (int32_t s = 0; s < S; ++s) {
+      int de = 0;
+      const double mm = frexp((double)arena[msg_index(in_k[i], t, S, s, tile, lt)], &de);
+      const double q = mant[s * 64 + lane] / mm;
+      int32_t x = expo[s * 64 + lane] - de;
+      if (q == 0.0) x = kDeadExponent;
+      quo[s * 64 + lane] = q;
+      qexp[s * 64 + lane] = x;
+      xmax = x > xmax ? x : xmax;
+    }
+    if (i == I - 1) {
+      for (int32_t s = 0; s < S; ++s)
+        arena[msg_index(dst, t, S, s, tile, lt)] =
+            (T)(ldexp(quo[s * 64 + lane], clamp_shift(qexp[s * 64 + lane] - emax)) / z);
+    } else {
+      double sum = 0.0;
+      for (int32_t s = 0; s < S; ++s) {
+        const double v = ldexp(quo[s * 64 + lane], clamp_shift(qexp[s * 64 + lane] - xmax));
+        quo[s * 64 + lane] = v;
+        sum += v;
+      }
+      for (int32_t s = 0; s < S; ++s) arena[msg_index(dst, t, S, s, tile, lt)] = (T)(quo[s * 64 + lane] / sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Factor pass: out_i[x_i] = sum over the other axes of cpt[x] * prod_{j != i} in_j[x_j]
+// for every slot i at once (FactorNodeGroup.calculate_outputs,
+// spa_v3/factor_graph.py:251-298, which issues one einsum per slot).  The CPT is walked
+// once in row-major order with an odometer; each entry is a wave-uniform scalar.
+//
+// grid.x = K * ntiles * (tile/64), block = 64, dynamic LDS = sum(dims)*64*(sizeof(T)+8).
+struct FactorDims {
+  int32_t arity;
+  int32_t d[kMaxArity];
+  int32_t base[kMaxArity];  // prefix sums of d
+  int32_t total;            // sum of d
+  int64_t elems;            // product of d
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) factor_pass_generic(T* __restrict__ arena, const T* __restrict__ cpts,
+                                                         const int64_t* __restrict__ in_off,
+                                                         const int64_t* __restrict__ out_off,
+                                                         const int64_t* __restrict__ cpt_off, int32_t K,
+                                                         FactorDims fd, int32_t tile, int64_t ntiles) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double* acc = reinterpret_cast<double*>(lds_raw);                       // [total][64]
+  T* in = reinterpret_cast<T*>(lds_raw + (size_t)fd.total * 64 * 8);      // [total][64]
+
+  const int32_t lane = threadIdx.x;
+  const int32_t subs = tile / 64;
+  int64_t w = blockIdx.x;
+  const int32_t sub = (int32_t)(w % subs);
+  w /= subs;
+  const int64_t t = w % ntiles;
+  const int32_t k = (int32_t)(w / ntiles);
+  if (k >= K) return;
+  const int32_t lt = sub * 64 + lane;
+  const int32_t A = fd.arity;
+
+#pragma unroll
+  for (int32_t j = 0; j < kMaxArity; ++j) {
+    if (j < A) {
+      const int64_t src = in_off[(int64_t)k * A + j];
+      for (int32_t x = 0; x < fd.d[j]; ++x) {
+        in[(fd.base[j] + x) * 64 + lane] = arena[msg_index(src, t, fd.d[j], x, tile, lt)];
+        acc[(fd.base[j] + x) * 64 + lane] = 0.0;
+      }
+    }
+  }
+
+  const T* cpt = cpts + cpt_off[k];
+  int32_t idx[kMaxArity];
+#pragma unroll
+  for (int32_t j = 0; j < kMaxArity; ++j) idx[j] = 0;
+
+  for (int64_t e = 0; e < fd.elems; ++e) {
+    const double c = (double)cpt[e];
+    double v[kMaxArity], pre[kMaxArity + 1], suf[kMaxArity + 1];
+    pre[0] = 1.0;
+#pragma unroll
+    for (int32_t j = 0; j < kMaxArity; ++j) {
+      v[j] = (j < A) ? (double)in[(fd.base[j] + idx[j]) * 64 + lane] : 1.0;
+      pre[j + 1] = pre[j] * v[j];
+    }
+    suf[kMaxArity] = 1.0;
+#pragma unroll
+    for (int32_t j = kMaxArity - 1; j >= 0; --j) suf[j] = suf[j + 1] * v[j];
+#pragma unroll
+    for (int32_t j = 0; j < kMaxArity; ++j) {
+      if (j < A) acc[(fd.base[j] + idx[j]) * 64 + lane] += c * pre[j] * suf[j + 1];
+    }
+    // advance the odometer, last axis fastest
+    bool carry = true;
+#pragma unroll
+    for (int32_t j = kMaxArity - 1; j >= 0; --j) {
+      if (j < A && carry) {
+        if (++idx[j] == fd.d[j]) {
+          idx[j] = 0;
+        } else {
+          carry = false;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int32_t j = 0; j < kMaxArity; ++j) {
+    if (j < A) {
+      const int64_t dst = out_off[(int64_t)k * A + j];
+      for (int32_t x = 0; x < fd.d[j]; ++x)
+        arena[msg_index(dst, t, fd.d[j], x, tile, lt)] = (T)acc[(fd.base[j] + x) * 64 + lane];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Evidence: ev[n, s] (row-major, caller's buffer) -> observation array in tile layout.
+// Pure copy, bit-exact (VariableNodeGroup.set_observations, spa_v3/factor_graph.py:166-170).
+// Padding observations get 1.0.   grid = (ceil(S*npad/256), num_observed), block = 256.
+template <typename T>
+__global__ void __launch_bounds__(256) evidence_scatter(T* __restrict__ arena,
+                                                       const void* const* __restrict__ sources,
+                                                       const int64_t* __restrict__ obs_off,
+                                                       const int32_t* __restrict__ obs_states, int64_t N,
+                                                       int32_t tile, int64_t ntiles) {
+  const int32_t o = blockIdx.y;
+  const int32_t S = obs_states[o];
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // position inside the array
+  if (idx >= (int64_t)S * ntiles * tile) return;
+  const int32_t lt = (int32_t)(idx % tile);
+  const int64_t rest = idx / tile;
+  const int32_t s = (int32_t)(rest % S);
+  const int64_t t = rest / S;
+  const int64_t n = t * tile + lt;
+  const T* src = static_cast<const T*>(sources[o]);
+  arena[obs_off[o] + idx] = n < N ? src[n * S + s] : (T)1;
+}
+
+// fill one region with a constant.  grid.x = ceil(count/256)
+template <typename T>
+__global__ void __launch_bounds__(256) fill_region(T* __restrict__ dst, int64_t count, T value) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < count) dst[idx] = value;
+}
+
+// fill many message arrays with 1/states.  grid = (ceil(max_elems/256), num_arrays)
+template <typename T>
+__global__ void __launch_bounds__(256) fill_uniform(T* __restrict__ arena, const int64_t* __restrict__ offs,
+                                                   const int32_t* __restrict__ states, int64_t npad) {
+  const int32_t a = blockIdx.y;
+  const int64_t count = (int64_t)states[a] * npad;
+  const T value = (T)1 / (T)states[a];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (int64_t)gridDim.x * 256)
+    arena[offs[a] + idx] = value;
+}
+
+// ---------------------------------------------------------------------------------
+// Tile layout -> row-major [N, S] product of up to two messages (single-node marginal,
+// SpaInferenceMachine._infer_single_node, spa_v3/spa_inference_machine.py:72-81; with
+// b_off < 0 it is a plain message read-out).   grid.x = ceil(N*S/256)
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ arena, int64_t a_off, int64_t b_off,
+                                                  T* __restrict__ out, int64_t N, int32_t S, int32_t tile) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * S) return;
+  const int64_t n = idx / S;
+  const int32_t s = (int32_t)(idx % S);
+  const int64_t t = n / tile;
+  const int32_t lt = (int32_t)(n % tile);
+  T v = arena[msg_index(a_off, t, S, s, tile, lt)];
+  if (b_off >= 0) v *= arena[msg_index(b_off, t, S, s, tile, lt)];
+  out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------
+// Family marginal, materialised: out[n, x] = cpt[x] * prod_j in_j[n, x_j]
+// (SpaInferenceMachine._infer_node_with_parents, spa_v3/spa_inference_machine.py:89-104).
+// grid.x = ceil(N*elems/256)
+struct FamilyArgs {
+  FactorDims fd;
+  int64_t in_off[kMaxArity];
+  int64_t cpt_off;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) family_marginal(const T* __restrict__ arena, const T* __restrict__ cpts,
+                                                      FamilyArgs fa, T* __restrict__ out, int64_t N,
+                                                      int32_t tile) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * fa.fd.elems) return;
+  const int64_t n = idx / fa.fd.elems;
+  int64_t e = idx % fa.fd.elems;
+  const int64_t t = n / tile;
+  const int32_t lt = (int32_t)(n % tile);
+  double prod = (double)cpts[fa.cpt_off + e];
+#pragma unroll
+  for (int32_t j = kMaxArity - 1; j >= 0; --j) {
+    if (j < fa.fd.arity) {
+      const int32_t x = (int32_t)(e % fa.fd.d[j]);
+      e /= fa.fd.d[j];
+      prod *= (double)arena[msg_index(fa.in_off[j], t, fa.fd.d[j], x, tile, lt)];
+    }
+  }
+  out[idx] = (T)prod;
+}
+
+// ---------------------------------------------------------------------------------
+// Sum of the normalisers c[node, n] over all nodes and the real observations.
+// Stage 1: grid.x blocks of 256 write one double each; stage 2 (one block) adds them in
+// index order, so the result does not depend on scheduling.
+template <typename T>
+__global__ void __launch_bounds__(256) ll_partial(const T* __restrict__ c, int64_t n_nodes, int64_t N,
+                                                 int64_t npad, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  const int64_t total = n_nodes * npad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t n = idx % npad;
+    if (n < N) acc += (double)c[idx];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) red[threadIdx.x] += red[threadIdx.x + step];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) sum_partials(const double* __restrict__ partial, int32_t count,
+                                                   double scale, double* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int32_t i = threadIdx.x; i < count; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) red[threadIdx.x] += red[threadIdx.x + step];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// ---------------------------------------------------------------------------------
+// EM expected counts, shape-agnostic: a thread owns one CPT entry x and sums
+// prod_j in_j[n, x_j] over the observations of the block's tile range; inputs for 64
+// observations at a time are staged in LDS as [row][65].  Output: one double per
+// (entry, tile chunk); em_finalize adds the chunks in order and applies the CPT factor.
+//
+// grid = (ceil(elems/256), nchunks, K), block = 256, dynamic LDS = total*65*sizeof(T).
+template <typename T>
+__global__ void __launch_bounds__(256) em_partial_generic(const T* __restrict__ arena,
+                                                         const int64_t* __restrict__ in_off, FactorDims fd,
+                                                         int64_t N, int32_t tile, int64_t ntiles,
+                                                         int32_t nchunks, double* __restrict__ partial,
+                                                         const int64_t* __restrict__ cpt_off) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* in = reinterpret_cast<T*>(lds_raw);  // [total][65]
+  const int32_t k = blockIdx.z;
+  const int32_t chunk = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t A = fd.arity;
+
+  int32_t row[kMaxArity];
+  {
+    int64_t r = e < fd.elems ? e : 0;
+#pragma unroll
+    for (int32_t j = kMaxArity - 1; j >= 0; --j) {
+      if (j < A) {
+        row[j] = fd.base[j] + (int32_t)(r % fd.d[j]);
+        r /= fd.d[j];
+      } else {
+        row[j] = 0;
+      }
+    }
+  }
+
+  const int32_t subs = tile / 64;
+  const int64_t slices = ntiles * subs;
+  const int64_t per = (slices + nchunks - 1) / nchunks;
+  const int64_t first = chunk * per;
+  const int64_t last = first + per < slices ? first + per : slices;
+
+  double acc = 0.0;
+  for (int64_t sl = first; sl < last; ++sl) {
+    const int64_t t = sl / subs;
+    const int32_t sub = (int32_t)(sl % subs);
+    const int64_t n0 = t * tile + sub * 64;
+    int32_t cnt = (int32_t)(N - n0 < 64 ? N - n0 : 64);
+    if (cnt <= 0) break;
+    __syncthreads();
+    for (int32_t r = threadIdx.x; r < fd.total * 64; r += 256) {
+      const int32_t rr = r / 64, ll = r % 64;
+      // which slot does row rr belong to
+      int32_t j = 0;
+#pragma unroll
+      for (int32_t q = 1; q < kMaxArity; ++q)
+        if (q < A && rr >= fd.base[q]) j = q;
+      in[rr * 65 + ll] =
+          arena[msg_index(in_off[(int64_t)k * A + j], t, fd.d[j], rr - fd.base[j], tile, sub * 64 + ll)];
+    }
+    __syncthreads();
+    if (e < fd.elems) {
+      for (int32_t n = 0; n < cnt; ++n) {
+        double prod = 1.0;
+#pragma unroll
+        for (int32_t j = 0; j < kMaxArity; ++j)
+          if (j < A) prod *= (double)in[row[j] * 65 + n];
+        acc += prod;
+      }
+    }
+  }
+  if (e < fd.elems) partial[(cpt_off[k] + e) * nchunks + chunk] = acc;
+}
+
+// accum[x] = cpt[x] * sum over chunks.   grid.x = ceil(total_entries/256)
+template <typename T>
+__global__ void __launch_bounds__(256) em_finalize(const double* __restrict__ partial, const T* __restrict__ cpts,
+                                                  int64_t entries, int32_t nchunks, double* __restrict__ accum) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= entries) return;
+  double acc = 0.0;
+  for (int32_t c = 0; c < nchunks; ++c) acc += partial[e * nchunks + c];
+  accum[e] = acc * (double)cpts[e];
+}
+
+}  // namespace bn

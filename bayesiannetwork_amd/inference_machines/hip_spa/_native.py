@@ -1,0 +1,102 @@
+"""ctypes binding of ``libbn_hip.so`` (C ABI in ``include/bn_hip.h``).
+
+The library is built in-tree by ``make`` / ``__graft_entry__.build()`` and is the
+only compute path: there is no CPU or eager fallback, and a missing library is
+an ``ImportError`` at first use.  ``torch`` is imported first so that the
+library binds to the HIP runtime PyTorch-ROCm already loaded (same SONAME),
+which makes ``tensor.data_ptr()`` addresses and torch streams directly usable.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (loads the HIP runtime the library must share)
+
+ABI_VERSION = 1
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "libbn_hip.so")
+_lib = None
+
+
+class BnError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def _declare(lib):
+    i32p = POINTER(c_int32)
+    lib.bn_abi_version.restype = c_int
+    lib.bn_abi_version.argtypes = []
+    lib.bn_last_error.restype = c_char_p
+    lib.bn_last_error.argtypes = []
+    lib.bn_plan_create.restype = c_int
+    lib.bn_plan_create.argtypes = [c_int, c_int64, c_int32, i32p, i32p, i32p, i32p, i32p, i32p, c_int32,
+                                   POINTER(c_void_p)]
+    lib.bn_plan_destroy.restype = c_int
+    lib.bn_plan_destroy.argtypes = [c_void_p]
+    lib.bn_plan_topology.restype = c_int
+    lib.bn_plan_topology.argtypes = [c_void_p, i32p, i32p]
+    lib.bn_plan_cpt_elements.restype = c_int64
+    lib.bn_plan_cpt_elements.argtypes = [c_void_p]
+    lib.bn_plan_device_bytes.restype = c_int64
+    lib.bn_plan_device_bytes.argtypes = [c_void_p]
+    lib.bn_set_cpts.restype = c_int
+    lib.bn_set_cpts.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.bn_reset_messages.restype = c_int
+    lib.bn_reset_messages.argtypes = [c_void_p, c_void_p]
+    lib.bn_enter_evidence.restype = c_int
+    lib.bn_enter_evidence.argtypes = [c_void_p, POINTER(c_void_p), c_void_p]
+    lib.bn_iterate.restype = c_int
+    lib.bn_iterate.argtypes = [c_void_p, c_int32, c_void_p]
+    lib.bn_log_likelihood.restype = c_int
+    lib.bn_log_likelihood.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+    lib.bn_local_log_likelihoods.restype = c_int
+    lib.bn_local_log_likelihoods.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+    lib.bn_marginal_single.restype = c_int
+    lib.bn_marginal_single.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+    lib.bn_marginal_family.restype = c_int
+    lib.bn_marginal_family.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+    lib.bn_em_accumulate.restype = c_int
+    lib.bn_em_accumulate.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.bn_get_message.restype = c_int
+    lib.bn_get_message.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+
+
+EXPORTS = (
+    "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
+    "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
+    "bn_enter_evidence", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
+    "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_get_message",
+)
+
+
+def load():
+    """The loaded library (cached).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
+                "there is no fallback path"
+            )
+        lib = ctypes.CDLL(_LIB_PATH)
+        _declare(lib)
+        if lib.bn_abi_version() != ABI_VERSION:
+            raise ImportError(f"libbn_hip.so ABI {lib.bn_abi_version()} != expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise BnError(load().bn_last_error().decode("utf-8", "replace"))
+
+
+def i32_array(values):
+    arr = (c_int32 * max(len(values), 1))(*values)
+    return arr

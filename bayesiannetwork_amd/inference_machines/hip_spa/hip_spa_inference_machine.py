@@ -1,0 +1,307 @@
+"""Sum-product inference machine whose arithmetic runs in gfx950 HIP kernels.
+
+Drop-in for the reference's ``SpaInferenceMachine``
+(``inference_machines/spa_v3/spa_inference_machine.py:23-137``): same
+constructor ``(settings, bayesian_network, observed_nodes, num_observations)``,
+same settings dataclass, same five ``IInferenceMachine`` members, same lazy
+evaluation (``enter_evidence`` only stores; the first query runs all
+iterations), same exceptions.  Everything below the interface — message
+buffers, both message passes, normalisers, marginals, EM statistics — lives in
+``libbn_hip.so`` behind the C ABI of ``include/bn_hip.h``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+
+from ...bayesian_network import BayesianNetwork, Node
+from ..abstractions import IInferenceMachine
+from ..common import InferenceMachineSettings
+from ..evidence import Evidence
+from . import _native
+
+
+@dataclass
+class SpaInferenceMachineSettings(InferenceMachineSettings):
+    num_iterations: Optional[int] = None
+    allow_loops: bool = False
+    callback: Optional[Callable[[int], None]] = None
+
+
+def _stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _FactorGraphView:
+    """``machine.factor_graph.G``: the undirected variable/factor graph
+    (``V_<name>`` / ``F_<name>`` vertices, as ``spa_v3/factor_graph.py:475-506``)."""
+
+    def __init__(self, network: BayesianNetwork):
+        self._network = network
+        self._G = None
+
+    @property
+    def G(self):
+        if self._G is None:
+            import networkx as nx
+
+            g = nx.Graph()
+            for node in self._network.nodes:
+                g.add_node(f"V_{node.name}", node=node)
+                g.add_node(f"F_{node.name}", node=node)
+            for node in self._network.nodes:
+                g.add_edge(f"V_{node.name}", f"F_{node.name}")
+            for parent, child in self._network.edges:
+                g.add_edge(f"V_{parent.name}", f"F_{child.name}")
+            self._G = g
+        return self._G
+
+
+class HipSpaInferenceMachine(IInferenceMachine):
+    def __init__(
+        self,
+        settings: SpaInferenceMachineSettings,
+        bayesian_network: BayesianNetwork,
+        observed_nodes: List[Node],
+        num_observations: int,
+    ):
+        ts = settings.torch_settings
+        if ts.device.type != "cuda":
+            raise ValueError(
+                "HipSpaInferenceMachine runs on an AMD GPU only (TorchSettings(device='cuda')); "
+                "there is no CPU path"
+            )
+        self._lib = _native.load()
+        self._settings = settings
+        self._network = bayesian_network
+        self.num_observations = num_observations
+        self.observed_nodes = list(observed_nodes)
+        self._device = torch.device("cuda", torch.cuda.current_device()) if ts.device.index is None else ts.device
+        self._dtype = ts.dtype
+        self._n = max(int(num_observations), 1)
+
+        nodes = list(bayesian_network.nodes)
+        self._nodes = nodes
+        self._index = {node: i for i, node in enumerate(nodes)}
+        states, p_off, p_idx, c_off, c_idx = [], [0], [], [0], []
+        for node in nodes:
+            states.append(int(node.num_states))
+            p_idx.extend(self._index[q] for q in bayesian_network.parents_of(node))
+            p_off.append(len(p_idx))
+            c_idx.extend(self._index[q] for q in bayesian_network.children_of(node))
+            c_off.append(len(c_idx))
+        observed = [self._index[o] for o in self.observed_nodes]
+        self._cpt_shapes = [tuple(node.cpt.shape) for node in nodes]
+
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_plan_create(
+                    0 if self._dtype == torch.float32 else 1,
+                    self._n,
+                    len(nodes),
+                    _native.i32_array(states),
+                    _native.i32_array(p_off),
+                    _native.i32_array(p_idx),
+                    _native.i32_array(c_off),
+                    _native.i32_array(c_idx),
+                    _native.i32_array(observed),
+                    len(observed),
+                    ctypes.byref(handle),
+                )
+            )
+        self._plan = handle
+
+        is_tree, diameter = ctypes.c_int32(), ctypes.c_int32()
+        _native.check(self._lib.bn_plan_topology(self._plan, ctypes.byref(is_tree), ctypes.byref(diameter)))
+        if is_tree.value:
+            self._num_iterations = settings.num_iterations if settings.num_iterations else diameter.value
+        else:
+            if not settings.allow_loops:
+                raise ValueError("Network contains loops, but the specified settings disallow them.")
+            if not settings.num_iterations:
+                raise ValueError("Networks containers loops; number of iterations must be set explicitly.")
+            self._num_iterations = settings.num_iterations
+
+        self.set_cpts([node.cpt for node in nodes])
+        self.factor_graph = _FactorGraphView(bayesian_network)
+        self.must_iterate: bool = True
+        self._evidence_keepalive = None
+
+    def __del__(self):
+        plan = getattr(self, "_plan", None)
+        if plan:
+            try:
+                self._lib.bn_plan_destroy(plan)
+            except Exception:
+                pass
+            self._plan = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(_stream_handle(self._device))
+
+    def set_cpts(self, cpts) -> None:
+        """Snapshot CPTs (one tensor per node, network order) into the plan."""
+        flat = torch.cat([c.detach().to(self._device, self._dtype).reshape(-1) for c in cpts])
+        if flat.numel() != self._lib.bn_plan_cpt_elements(self._plan):
+            raise ValueError("CPT sizes do not match the network the machine was built for")
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_set_cpts(self._plan, ctypes.c_void_p(flat.data_ptr()), self._stream()))
+        self._cpt_keepalive = flat
+        self.must_iterate = True
+
+    @property
+    def settings(self) -> InferenceMachineSettings:
+        return self._settings
+
+    @property
+    def num_iterations(self) -> int:
+        return self._num_iterations
+
+    # ------------------------------------------------------------------ interface
+    def enter_evidence(self, evidence: Evidence) -> None:
+        tensors = [
+            t.detach().to(self._device, self._dtype).contiguous() for t in evidence.data
+        ]
+        if len(tensors) != len(self.observed_nodes):
+            raise ValueError("evidence must hold one tensor per observed node")
+        for t, node in zip(tensors, self.observed_nodes):
+            if tuple(t.shape) != (self._n, node.num_states):
+                raise RuntimeError(
+                    f"evidence for node {node} has shape {tuple(t.shape)}, expected {(self._n, node.num_states)}"
+                )
+        table = (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_enter_evidence(self._plan, table, self._stream()))
+        self._evidence_keepalive = tensors
+        self.must_iterate = True
+
+    def _iterate(self) -> None:
+        callback = self._settings.callback
+        with torch.cuda.device(self._device):
+            if callback:
+                for iteration in range(self._num_iterations):
+                    _native.check(self._lib.bn_iterate(self._plan, 1, self._stream()))
+                    callback(iteration)
+            else:
+                _native.check(self._lib.bn_iterate(self._plan, self._num_iterations, self._stream()))
+        self.must_iterate = False
+
+    def infer_single_nodes(self, nodes: List[Node]) -> List[torch.Tensor]:
+        if self.must_iterate:
+            self._iterate()
+        out = []
+        with torch.cuda.device(self._device):
+            for node in nodes:
+                p = torch.empty((self._n, node.num_states), device=self._device, dtype=self._dtype)
+                _native.check(
+                    self._lib.bn_marginal_single(self._plan, self._index[node], ctypes.c_void_p(p.data_ptr()),
+                                                 self._stream())
+                )
+                out.append(p)
+        return out
+
+    def infer_nodes_with_parents(self, child_nodes: List[Node]) -> List[torch.Tensor]:
+        if self.must_iterate:
+            self._iterate()
+        out = []
+        with torch.cuda.device(self._device):
+            for node in child_nodes:
+                j = self._index[node]
+                p = torch.empty((self._n,) + self._cpt_shapes[j], device=self._device, dtype=self._dtype)
+                _native.check(
+                    self._lib.bn_marginal_family(self._plan, j, ctypes.c_void_p(p.data_ptr()), self._stream())
+                )
+                out.append(p)
+        return out
+
+    def log_likelihood(self) -> float:
+        if not self.observed_nodes:
+            raise Exception("Log likelihood can't be calculated with 0 observed nodes")
+        return self.log_likelihood_tensor().item()
+
+    # ------------------------------------------------------------------ extensions
+    def log_likelihood_tensor(self) -> torch.Tensor:
+        """Log-likelihood as a one-element float64 device tensor (no host sync)."""
+        if self.must_iterate:
+            self._iterate()
+        out = torch.empty((1,), device=self._device, dtype=torch.float64)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_log_likelihood(self._plan, 1 if self._settings.average_log_likelihood else 0,
+                                            ctypes.c_void_p(out.data_ptr()), self._stream())
+            )
+        return out
+
+    def expected_count_sums(self) -> torch.Tensor:
+        """EM statistic: for every node the sum over observations of its family marginal, as one
+        flat float64 device tensor laid out like the concatenated CPTs (network order).
+        ``split_counts`` cuts it into CPT-shaped views."""
+        if self.must_iterate:
+            self._iterate()
+        total = self._lib.bn_plan_cpt_elements(self._plan)
+        out = torch.empty((total,), device=self._device, dtype=torch.float64)
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_em_accumulate(self._plan, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def split_counts(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        views, pos = [], 0
+        for shape in self._cpt_shapes:
+            size = 1
+            for d in shape:
+                size *= d
+            views.append(flat[pos : pos + size].reshape(shape))
+            pos += size
+        return views
+
+    def local_log_likelihoods(self, node: Node) -> torch.Tensor:
+        if self.must_iterate:
+            self._iterate()
+        out = torch.empty((self._n,), device=self._device, dtype=self._dtype)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_local_log_likelihoods(self._plan, self._index[node], ctypes.c_void_p(out.data_ptr()),
+                                                   self._stream())
+            )
+        return out
+
+    def message(self, variable: Node, factor_owner: Node, direction: str) -> torch.Tensor:
+        """``[N, S]`` copy of the message on the edge between ``variable`` and the factor of
+        ``factor_owner``; ``direction`` is ``"v2f"`` or ``"f2v"``.  Does not trigger iteration."""
+        owner = self._index[factor_owner]
+        if variable is factor_owner:
+            slot = -1
+        else:
+            slot = list(self._network.parents_of(factor_owner)).index(variable)
+        out = torch.empty((self._n, variable.num_states), device=self._device, dtype=self._dtype)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_get_message(self._plan, owner, slot, 0 if direction == "v2f" else 1,
+                                         ctypes.c_void_p(out.data_ptr()), self._stream())
+            )
+        return out
+
+    def observation(self, node: Node) -> torch.Tensor:
+        """``[N, S]`` copy of what the observation slot of an observed node currently holds."""
+        out = torch.empty((self._n, node.num_states), device=self._device, dtype=self._dtype)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_get_message(self._plan, self._index[node], -2, 0, ctypes.c_void_p(out.data_ptr()),
+                                         self._stream())
+            )
+        return out
+
+    def reset_messages(self) -> None:
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_reset_messages(self._plan, self._stream()))
+        self.must_iterate = True
+
+    @property
+    def device_bytes(self) -> int:
+        return self._lib.bn_plan_device_bytes(self._plan)

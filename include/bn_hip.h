@@ -1,0 +1,169 @@
+/*
+ * bn_hip.h — C ABI of the MI355X (gfx950) sum-product / EM engine.
+ *
+ * One shared library, libbn_hip.so, plain pointers and sizes only.  Every
+ * function returns 0 on success and a negative code on failure;
+ * bn_last_error() then holds a message for the calling thread.  Device
+ * pointers are ordinary HIP device addresses (e.g. tensor.data_ptr()); the
+ * stream argument is a hipStream_t passed as void* (NULL = default stream).
+ * A plan is bound to the HIP device it was created on, owns all message
+ * buffers, and is not thread-safe; the caller keeps input/output buffers
+ * alive until the stream has run the call.
+ *
+ * The reference package has no FFI layer: its seam is the Python ABC
+ * IInferenceMachine (inference_machines/abstractions.py:13-33) implemented by
+ * spa_v3/spa_inference_machine.py.  Each entry point below names the piece of
+ * that implementation it replaces.
+ *
+ * Layout conventions
+ *   - node ids index the network's node order (BayesianNetwork.nodes,
+ *     bayesian_network.py:46-48);
+ *   - a CPT is row-major [parent_0, ..., parent_{P-1}, states]
+ *     (bayesian_network.py:17-23); "flat CPT buffer" = all CPTs concatenated in
+ *     node order, in the plan's dtype;
+ *   - evidence / marginals handed across this boundary are row-major
+ *     [num_observations, ...] exactly as the reference's tensors.
+ */
+#ifndef BN_HIP_H
+#define BN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bn_plan bn_plan;
+
+enum { BN_F32 = 0, BN_F64 = 1 };
+
+enum {
+  BN_OK = 0,
+  BN_ERR_INVALID = -1, /* bad argument / inconsistent topology */
+  BN_ERR_HIP = -2,     /* a HIP runtime call failed */
+  BN_ERR_STATE = -3    /* call not valid in the plan's current state */
+};
+
+/* ABI version of this header (bumped on any signature change). */
+int bn_abi_version(void);
+
+/* Message for the last failure on this thread (never NULL). */
+const char* bn_last_error(void);
+
+/*
+ * Compile a plan: grouping of variable / factor nodes, message arena,
+ * per-group index tables, uniform initial messages.
+ * Replaces FactorGraph.__init__ + VariableNodeGroup/FactorNodeGroup.__init__
+ * (spa_v3/factor_graph.py:327-424, :15-110, :174-249).
+ *
+ *   dtype              BN_F32 / BN_F64
+ *   num_observations   N >= 1 (the reference maps 0 to 1, factor_graph.py:34-35)
+ *   num_states[j]      states of node j
+ *   parent_offsets     CSR offsets, num_nodes+1 entries
+ *   parent_indices     parents of node j in CPT axis order
+ *   child_offsets/child_indices
+ *                      children of node j in variable-slot order
+ *                      (BayesianNetwork.children_of order)
+ *   observed_nodes     node ids in evidence order
+ */
+int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const int32_t* num_states,
+                   const int32_t* parent_offsets, const int32_t* parent_indices,
+                   const int32_t* child_offsets, const int32_t* child_indices,
+                   const int32_t* observed_nodes, int32_t num_observed, bn_plan** out_plan);
+
+int bn_plan_destroy(bn_plan* plan);
+
+/*
+ * Topology facts computed by the plan compiler; replace nx.is_tree(network.G)
+ * and nx.diameter(factor_graph.G) (spa_v3/spa_inference_machine.py:41-46).
+ * diameter is -1 when the factor graph is not connected.
+ */
+int bn_plan_topology(const bn_plan* plan, int32_t* is_tree, int32_t* factor_graph_diameter);
+
+/* Total element count of the flat CPT buffer / of the EM statistics buffer. */
+int64_t bn_plan_cpt_elements(const bn_plan* plan);
+
+/* Bytes of device memory the plan holds (message arena + tables + scratch). */
+int64_t bn_plan_device_bytes(const bn_plan* plan);
+
+/*
+ * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
+ * Replaces torch.stack(node.cpt ...) in FactorNodeGroup.__init__
+ * (spa_v3/factor_graph.py:192).
+ */
+int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream);
+
+/* Put every message back to uniform 1/S, as after construction
+ * (spa_v3/factor_graph.py:48-60, :197-213). */
+int bn_reset_messages(bn_plan* plan, void* stream);
+
+/*
+ * Copy evidence into the observation slot of every observed node.
+ * evidence_dev[i] is the device address of a contiguous
+ * [num_observations, num_states(observed_nodes[i])] array in the plan dtype;
+ * the array of addresses itself lives in host memory.  Values are copied
+ * bit-for-bit.  Replaces FactorGraph.enter_evidence +
+ * VariableNodeGroup.set_observations (spa_v3/factor_graph.py:453-473, :166-170).
+ */
+int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stream);
+
+/*
+ * Run num_iterations flooding iterations: all variable-to-factor updates, then
+ * all factor-to-variable updates.  Replaces FactorGraph.iterate,
+ * VariableNodeGroup.calculate_outputs and FactorNodeGroup.calculate_outputs
+ * (spa_v3/factor_graph.py:446-451, :112-144, :251-298).
+ */
+int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream);
+
+/*
+ * Sum over nodes and observations of the per-node normalisers c[node, n]
+ * written by the last variable pass; divided by num_observations when
+ * average != 0.  One double is written to out_dev.  Replaces
+ * SpaInferenceMachine.log_likelihood (spa_v3/spa_inference_machine.py:128-137).
+ */
+int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* stream);
+
+/* c[node, :] -> out_dev[num_observations] (plan dtype).  Replaces reading
+ * VariableNodeGroup.local_log_likelihoods (spa_v3/factor_graph.py:144). */
+int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* stream);
+
+/*
+ * out_dev[N, S] = (local factor -> variable message) * (variable -> local
+ * factor message).  Replaces SpaInferenceMachine._infer_single_node
+ * (spa_v3/spa_inference_machine.py:72-81).
+ */
+int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream);
+
+/*
+ * out_dev[N, d_0..d_{P-1}, S] = cpt * product of the factor's input messages
+ * (not renormalised).  Replaces SpaInferenceMachine._infer_node_with_parents
+ * (spa_v3/spa_inference_machine.py:89-104).
+ */
+int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream);
+
+/*
+ * EM expected counts: for every node the SUM over observations of its family
+ * marginal, written as doubles to accum_dev laid out like the flat CPT buffer.
+ * Dividing by num_observations gives exactly
+ * infer_nodes_with_parents(all nodes)[i].mean(dim=0)
+ * (optimizers/em_batch_optimizer.py:61-68, optimizers/em_optimizer.py:48-55)
+ * without materialising the [N, ...] tensors.
+ */
+int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream);
+
+/*
+ * Inspection: copy one message out as [N, S].
+ *   owner      node whose factor is one end of the edge
+ *   slot       -1 = edge to the owner's own variable, p >= 0 = edge to its p-th parent,
+ *              -2 = the observation slot of `owner` (must be observed; direction ignored)
+ *   direction  0 = variable -> factor, 1 = factor -> variable
+ * Corresponds to reading FactorNodeGroup/VariableNodeGroup.get_input_tensor
+ * (spa_v3/factor_graph.py:156-164, :310-318).
+ */
+int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction, void* out_dev,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN_HIP_H */
