@@ -4,6 +4,8 @@
 #include "../../include/bn_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -69,6 +71,65 @@ bn::FactorDims make_dims(const std::vector<int32_t>& dims) {
 }
 
 constexpr int64_t kLdsLimit = 158 * 1024;
+
+struct ProfRecord {
+  std::string label;
+  double alg_bytes;
+  hipEvent_t start, stop;
+};
+std::mutex g_prof_mutex;
+std::vector<ProfRecord> g_prof;
+std::atomic<bool> g_profiling{false};
+
+void prof_begin(const std::string& label, double alg_bytes, hipStream_t s) {
+  if (!g_profiling.load(std::memory_order_relaxed)) return;
+  ProfRecord r;
+  r.label = label;
+  r.alg_bytes = alg_bytes;
+  if (hipEventCreate(&r.start) != hipSuccess) return;
+  if (hipEventCreate(&r.stop) != hipSuccess) {
+    (void)hipEventDestroy(r.start);
+    return;
+  }
+  (void)hipEventRecord(r.start, s);
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof.push_back(std::move(r));
+}
+
+void prof_end(hipStream_t s) {
+  if (!g_profiling.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().stop, s);
+}
+
+// Compulsory bytes of one launch (see bn_profile_report in bn_hip.h).
+double variable_bytes(const bn::Plan& p, const bn::VariableGroup& g) {
+  double per_obs = 0;
+  for (size_t k = 0; k < g.nodes.size(); ++k) {
+    int32_t live_out = 0;
+    for (int32_t i = 0; i < g.num_inputs; ++i) live_out += g.out_off[k * g.num_inputs + i] >= 0;
+    per_obs += (double)g.num_states * g.num_inputs + (double)g.num_states * live_out + 1;
+  }
+  return per_obs * (double)p.N * (double)p.elem_size;
+}
+
+double factor_bytes(const bn::Plan& p, const bn::FactorGroup& g, bool read_only) {
+  double total = 0;
+  for (int32_t d : g.dims) total += d;
+  double per_node = g.dims.size() == 1 ? (read_only ? 0 : total) : (read_only ? total : 2 * total);
+  return per_node * (double)g.nodes.size() * (double)p.N * (double)p.elem_size;
+}
+
+std::string vlabel(const bn::VariableGroup& g) {
+  return "variable_pass[I=" + std::to_string(g.num_inputs) + ",S=" + std::to_string(g.num_states) +
+         ",K=" + std::to_string(g.nodes.size()) + "]";
+}
+
+std::string flabel(const char* what, const bn::FactorGroup& g) {
+  std::string l = std::string(what) + "[";
+  for (size_t i = 0; i < g.dims.size(); ++i) l += (i ? "x" : "") + std::to_string(g.dims[i]);
+  return l + ",K=" + std::to_string(g.nodes.size()) + "]";
+}
 constexpr int32_t kLlBlocks = 1024;
 
 void release(bn::Plan& p) {
@@ -102,22 +163,40 @@ int32_t em_chunks(const bn::Plan& p) {
 }
 
 template <typename T>
+int fill_arrays(bn::Plan& p, int64_t first_array, int64_t count, hipStream_t s) {
+  T* arena = static_cast<T*>(p.arena);
+  if (count <= 0) return BN_OK;
+  const int64_t max_elems = (int64_t)p.fill_max_states * p.npad;
+  const int32_t gx = (int32_t)std::min<int64_t>((max_elems + 255) / 256, 4096);
+  for (int64_t first = 0; first < count; first += 65535) {
+    const int32_t cnt = (int32_t)std::min<int64_t>(count - first, 65535);
+    hipLaunchKernelGGL(bn::fill_uniform<T>, dim3(gx, cnt), dim3(256), 0, s, arena,
+                       p.d_fill_off + first_array + first, p.d_fill_states + first_array + first, p.npad);
+    BN_LAUNCH_CHECK("fill_uniform");
+  }
+  return BN_OK;
+}
+
+// Back to the state right after construction.  Observation slots and normalisers are
+// written now; the message arrays only get marked (Plan::fresh) and are filled on demand.
+template <typename T>
 int reset_messages_t(bn::Plan& p, hipStream_t s) {
   T* arena = static_cast<T*>(p.arena);
-  const int32_t arrays = (int32_t)p.fill_count;
-  if (arrays > 0) {
-    int64_t max_elems = (int64_t)p.fill_max_states * p.npad;
-    int32_t gx = (int32_t)std::min<int64_t>((max_elems + 255) / 256, 4096);
-    for (int32_t first = 0; first < arrays; first += 65535) {
-      int32_t cnt = std::min(arrays - first, 65535);
-      hipLaunchKernelGGL(bn::fill_uniform<T>, dim3(gx, cnt), dim3(256), 0, s, arena, p.d_fill_off + first,
-                         p.d_fill_states + first, p.npad);
-      BN_LAUNCH_CHECK("fill_uniform");
-    }
-  }
+  int rc = fill_arrays<T>(p, p.fill_messages, p.fill_count - p.fill_messages, s);
+  if (rc != BN_OK) return rc;
   const int64_t c_elems = (int64_t)p.n_nodes * p.npad;
   BN_HIP_CHECK(hipMemsetAsync(arena + p.c_base, 0, c_elems * sizeof(T), s));
+  p.fresh = true;
   return BN_OK;
+}
+
+// Anything that reads message arrays directly needs them to hold real values.
+int materialize(bn::Plan& p, hipStream_t s) {
+  if (!p.fresh) return BN_OK;
+  int rc = p.dtype == BN_F32 ? fill_arrays<float>(p, 0, p.fill_messages, s)
+                             : fill_arrays<double>(p, 0, p.fill_messages, s);
+  if (rc == BN_OK) p.fresh = false;
+  return rc;
 }
 
 template <typename T>
@@ -126,9 +205,11 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
   const T* cpts = static_cast<const T*>(p.cpts);
   const int32_t subs = p.tile / 64;
   for (int32_t it = 0; it < iterations; ++it) {
+    const int32_t fresh = p.fresh ? 1 : 0;
     for (auto& g : p.vgroups) {
       const int32_t K = (int32_t)g.nodes.size();
-      int rc = bn::launch_variable_fast<T>(p, g, arena, s);
+      prof_begin(vlabel(g), variable_bytes(p, g), s);
+      int rc = bn::launch_variable_fast<T>(p, g, arena, fresh, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised variable kernel failed");
       if (rc == 0) {
         const int64_t blocks = (int64_t)K * p.ntiles * subs;
@@ -137,12 +218,15 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
           BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::variable_pass_generic<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bn::variable_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, g.d_in,
-                           g.d_out, g.d_c, K, g.num_inputs, g.num_states, p.tile, p.ntiles);
+                           g.d_out, g.d_c, K, g.num_inputs, g.num_states, p.tile, p.ntiles, fresh);
         BN_LAUNCH_CHECK("variable_pass_generic");
       }
+      prof_end(s);
     }
+    p.fresh = false;  // every variable -> factor message has been written; the factor pass writes the rest
     for (auto& g : p.fgroups) {
       const int32_t K = (int32_t)g.nodes.size();
+      prof_begin(flabel("factor_pass", g), factor_bytes(p, g, false), s);
       int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
       if (rc == 0) {
@@ -156,6 +240,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
                            g.d_in, g.d_out, g.d_cpt, K, fd, p.tile, p.ntiles);
         BN_LAUNCH_CHECK("factor_pass_generic");
       }
+      prof_end(s);
     }
   }
   return BN_OK;
@@ -169,9 +254,13 @@ int em_accumulate_t(bn::Plan& p, double* accum, hipStream_t s) {
   double* partial = p.scratch + kLlBlocks;
   for (auto& g : p.fgroups) {
     const int32_t K = (int32_t)g.nodes.size();
+    prof_begin(flabel("em_counts", g), factor_bytes(p, g, true), s);
     int rc = bn::launch_em_fast<T>(p, g, arena, nchunks, partial, s);
     if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised EM kernel failed");
-    if (rc > 0) continue;
+    if (rc > 0) {
+      prof_end(s);
+      continue;
+    }
     bn::FactorDims fd = make_dims(g.dims);
     const size_t lds = (size_t)fd.total * 65 * sizeof(T);
     if (lds > 48 * 1024)
@@ -185,10 +274,13 @@ int em_accumulate_t(bn::Plan& p, double* accum, hipStream_t s) {
                          g.d_cpt + first);
       BN_LAUNCH_CHECK("em_partial_generic");
     }
+    prof_end(s);
   }
+  prof_begin("em_finalize", 0.0, s);
   hipLaunchKernelGGL(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
                      cpts, p.cpt_total, nchunks, accum);
   BN_LAUNCH_CHECK("em_finalize");
+  prof_end(s);
   return BN_OK;
 }
 
@@ -294,6 +386,8 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
       sts.push_back(p.states[p.observed[i]]);
     }
     p.fill_count = (int64_t)offs.size();
+    p.fill_messages = 2 * (int64_t)p.edges.size();
+    for (size_t i = 0; i < p.observed.size(); ++i) max_states = std::max(max_states, p.states[p.observed[i]]);
     p.fill_max_states = max_states;
     BN_TRY(upload(offs, &p.d_fill_off, p.device_bytes));
     BN_TRY(upload(sts, &p.d_fill_states, p.device_bytes));
@@ -363,6 +457,11 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   std::memcpy(p.h_evidence_ptrs, evidence_dev, count * sizeof(void*));
   BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, p.h_evidence_ptrs, count * sizeof(void*), hipMemcpyHostToDevice, s));
   const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
+  {
+    double bytes = 0;
+    for (int32_t o : p.observed) bytes += (double)p.states[o] * (double)p.N * (double)p.elem_size;
+    prof_begin("evidence_scatter", bytes, s);
+  }
   for (size_t first = 0; first < count; first += 65535) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
     if (p.dtype == BN_F32) {
@@ -376,6 +475,7 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
     }
     BN_LAUNCH_CHECK("evidence_scatter");
   }
+  prof_end(s);
   return BN_OK;
 }
 
@@ -394,6 +494,7 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t total = (int64_t)p.n_nodes * p.npad;
   const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
+  prof_begin("log_likelihood", (double)p.n_nodes * (double)p.N * (double)p.elem_size, s);
   if (p.dtype == BN_F32) {
     hipLaunchKernelGGL(bn::ll_partial<float>, dim3(blocks), dim3(256), 0, s,
                        static_cast<const float*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
@@ -405,6 +506,7 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   const double scale = average ? 1.0 / (double)p.N : 1.0;
   hipLaunchKernelGGL(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, scale, out_dev);
   BN_LAUNCH_CHECK("sum_partials");
+  prof_end(s);
   return BN_OK;
 }
 
@@ -434,6 +536,7 @@ int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream)
   bn::Plan& p = plan->p;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   const bn::EdgeLayout& e = p.edges[node];
+  if (int rc = materialize(p, static_cast<hipStream_t>(stream))) return rc;
   return gather(p, e.f2v, e.v2f, e.states, out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -449,6 +552,7 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
   if (slot < -1 || slot >= (int32_t)p.parents[owner].size()) return fail(BN_ERR_INVALID, "slot out of range");
   if (direction != 0 && direction != 1) return fail(BN_ERR_INVALID, "direction must be 0 or 1");
   const bn::EdgeLayout& e = slot < 0 ? p.edges[owner] : p.edges[p.parent_edge_base[owner] + slot];
+  if (int rc = materialize(p, static_cast<hipStream_t>(stream))) return rc;
   return gather(p, direction == 0 ? e.v2f : e.f2v, -1, e.states, out_dev, static_cast<hipStream_t>(stream));
 }
 
@@ -458,6 +562,7 @@ int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream)
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = materialize(p, s)) return rc;
   bn::FamilyArgs fa{};
   fa.fd = make_dims(p.cpt_dims[node]);
   for (size_t q = 0; q < p.parents[node].size(); ++q) fa.in_off[q] = p.edges[p.parent_edge_base[node] + q].v2f;
@@ -482,7 +587,52 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream) {
   bn::Plan& p = plan->p;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = materialize(p, s)) return rc;
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, s) : em_accumulate_t<double>(p, accum_dev, s);
+}
+
+int bn_profile_enable(int32_t enabled) {
+  g_profiling.store(enabled != 0);
+  return BN_OK;
+}
+
+int bn_profile_report(char* buffer, int64_t capacity) {
+  if (!buffer || capacity < 3) return fail(BN_ERR_INVALID, "bad argument");
+  std::vector<ProfRecord> records;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    records.swap(g_prof);
+  }
+  std::vector<std::string> labels;
+  std::vector<double> total_ms, alg_bytes;
+  std::vector<int64_t> launches;
+  for (auto& r : records) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      size_t i = std::find(labels.begin(), labels.end(), r.label) - labels.begin();
+      if (i == labels.size()) {
+        labels.push_back(r.label);
+        total_ms.push_back(0.0);
+        launches.push_back(0);
+        alg_bytes.push_back(r.alg_bytes);
+      }
+      total_ms[i] += ms;
+      launches[i] += 1;
+    }
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  std::string json = "[";
+  for (size_t i = 0; i < labels.size(); ++i) {
+    char num[160];
+    std::snprintf(num, sizeof(num), "\", \"launches\": %lld, \"total_ms\": %.6f, \"alg_bytes\": %.1f}",
+                  (long long)launches[i], total_ms[i], alg_bytes[i]);
+    json += std::string(i ? ", " : "") + "{\"kernel\": \"" + labels[i] + num;
+  }
+  json += "]";
+  if ((int64_t)json.size() + 1 > capacity) json = "[]";
+  std::memcpy(buffer, json.c_str(), json.size() + 1);
+  return BN_OK;
 }
 
 }  // extern "C"

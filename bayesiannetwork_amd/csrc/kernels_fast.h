@@ -14,7 +14,7 @@ inline int prepare_fast(Plan&) { return 0; }
 inline void release_fast(Plan&) {}
 
 template <typename T>
-int launch_variable_fast(Plan&, VariableGroup&, T*, hipStream_t) {
+int launch_variable_fast(Plan&, VariableGroup&, T*, int32_t /*fresh*/, hipStream_t) {
   return 0;
 }
 

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
                                                            const int64_t* __restrict__ out_off,
                                                            const int64_t* __restrict__ c_off, int32_t K,
                                                            int32_t I, int32_t S, int32_t tile,
-                                                           int64_t ntiles) {
+                                                           int64_t ntiles, int32_t fresh) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double* mant = reinterpret_cast<double*>(lds_raw);                       // [S][64]
   double* quo = mant + (size_t)S * 64;                                     // [S][64]
@@ -85,6 +85,13 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
 
   const int64_t* in_k = in_off + (int64_t)k * I;
   const int64_t* out_k = out_off + (int64_t)k * I;
+  // while the plan is fresh, messages from factors still have their initial value 1/S and
+  // are not read (the observation slot, whose output offset is -1, always is)
+  const T uniform = (T)1 / (T)S;
+  auto input = [&](int32_t i, int32_t s) -> T {
+    if (fresh && out_k[i] >= 0) return uniform;
+    return arena[msg_index(in_k[i], t, S, s, tile, lt)];
+  };
 
   // P[s] as mantissa * 2^exponent
   int32_t emax = kDeadExponent;
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
     double m = 1.0;
     int32_t e = 0;
     for (int32_t i = 0; i < I; ++i) {
-      m *= (double)arena[msg_index(in_k[i], t, S, s, tile, lt)];
+      m *= (double)input(i, s);
       if ((i & 3) == 3 || i == I - 1) {
         int de = 0;
         m = frexp(m, &de);
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
     int32_t xmax = kDeadExponent;
     for (int32_t s = 0; s < S; ++s) {
       int de = 0;
-      const double mm = frexp((double)arena[msg_index(in_k[i], t, S, s, tile, lt)], &de);
+      const double mm = frexp((double)input(i, s), &de);
       const double q = mant[s * 64 + lane] / mm;
       int32_t x = expo[s * 64 + lane] - de;
       if (q == 0.0) x = kDeadExponent;

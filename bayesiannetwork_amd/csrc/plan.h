@@ -101,9 +101,14 @@ struct Plan {
   int64_t* d_fill_off = nullptr;    // every message / observation array, for the uniform reset
   int32_t* d_fill_states = nullptr;
   int64_t fill_count = 0;
+  int64_t fill_messages = 0;  // the first fill_messages arrays are messages, the rest observation slots
   int32_t fill_max_states = 1;
   int64_t device_bytes = 0;
   bool cpts_set = false;
+  // true while every message still has its initial uniform value and the arrays have not
+  // been written: the first variable pass then uses 1/S directly instead of reading them
+  bool fresh = false;
+
 };
 
 // Builds everything host-side (no HIP calls).  Returns "" or an error message.

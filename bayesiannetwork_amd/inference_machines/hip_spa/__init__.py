@@ -1,3 +1,8 @@
-from .hip_spa_inference_machine import HipSpaInferenceMachine, SpaInferenceMachineSettings
+from .hip_spa_inference_machine import (
+    HipSpaInferenceMachine,
+    SpaInferenceMachineSettings,
+    enable_profiling,
+    profile_report,
+)
 
-__all__ = ["HipSpaInferenceMachine", "SpaInferenceMachineSettings"]
+__all__ = ["HipSpaInferenceMachine", "SpaInferenceMachineSettings", "enable_profiling", "profile_report"]

@@ -65,6 +65,10 @@ def _declare(lib):
     lib.bn_em_accumulate.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.bn_get_message.restype = c_int
     lib.bn_get_message.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.bn_profile_enable.restype = c_int
+    lib.bn_profile_enable.argtypes = [c_int32]
+    lib.bn_profile_report.restype = c_int
+    lib.bn_profile_report.argtypes = [c_char_p, c_int64]
 
 
 EXPORTS = (
@@ -72,6 +76,7 @@ EXPORTS = (
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_get_message",
+    "bn_profile_enable", "bn_profile_report",
 )
 
 

@@ -36,6 +36,23 @@ def _stream_handle(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _flatten_cpts(cpts, device, dtype) -> torch.Tensor:
+    """Concatenate CPT tensors; free when they already are consecutive views of one buffer
+    (what the EM optimizers hand back), one ``torch.cat`` otherwise."""
+    first = cpts[0]
+    base = getattr(first, "_base", None)
+    if base is not None and base.dim() == 1 and base.device == device and base.dtype == dtype and base.is_contiguous():
+        pos = 0
+        for c in cpts:
+            if getattr(c, "_base", None) is not base or c.storage_offset() != pos or not c.is_contiguous():
+                break
+            pos += c.numel()
+        else:
+            if pos == base.numel():
+                return base
+    return torch.cat([c.detach().to(device, dtype).reshape(-1) for c in cpts])
+
+
 class _FactorGraphView:
     """``machine.factor_graph.G``: the undirected variable/factor graph
     (``V_<name>`` / ``F_<name>`` vertices, as ``spa_v3/factor_graph.py:475-506``)."""
@@ -61,6 +78,62 @@ class _FactorGraphView:
         return self._G
 
 
+def enable_profiling(enabled: bool = True) -> None:
+    """Process-wide: bracket every kernel launch with HIP events (benchmark use)."""
+    _native.check(_native.load().bn_profile_enable(1 if enabled else 0))
+
+
+def profile_report():
+    """``[{"kernel", "launches", "total_ms", "alg_bytes"}, ...]`` since the last report."""
+    import json
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    _native.check(_native.load().bn_profile_report(buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
+class _PlanHandle:
+    """Owns one ``bn_plan``; destroys it when the last reference goes away."""
+
+    def __init__(self, lib, handle):
+        self.lib = lib
+        self.handle = handle
+
+    def __del__(self):
+        if self.handle:
+            try:
+                self.lib.bn_plan_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class _Topology:
+    """Everything derived from (network, observed nodes, N, dtype, device) that does not
+    depend on CPT values; shared by all machines built for that combination, together
+    with a small pool of idle plans.  Optimizers build a new machine every EM step
+    (``optimizers/em_batch_optimizer.py:41`` of the reference); with the pool that costs a
+    message reset and a CPT upload instead of a plan compilation and a device allocation."""
+
+    MAX_IDLE = 2
+
+    def __init__(self, network: BayesianNetwork, observed_nodes: List[Node]):
+        self.nodes = list(network.nodes)
+        self.index = {node: i for i, node in enumerate(self.nodes)}
+        self.states, self.p_off, self.p_idx, self.c_off, self.c_idx = [], [0], [], [0], []
+        for node in self.nodes:
+            self.states.append(int(node.num_states))
+            self.p_idx.extend(self.index[q] for q in network.parents_of(node))
+            self.p_off.append(len(self.p_idx))
+            self.c_idx.extend(self.index[q] for q in network.children_of(node))
+            self.c_off.append(len(self.c_idx))
+        self.observed = [self.index[o] for o in observed_nodes]
+        self.cpt_shapes = [tuple(node.cpt.shape) for node in self.nodes]
+        self.idle: List[_PlanHandle] = []
+        self.is_tree = None
+        self.diameter = None
+
+
 class HipSpaInferenceMachine(IInferenceMachine):
     def __init__(
         self,
@@ -84,42 +157,48 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self._dtype = ts.dtype
         self._n = max(int(num_observations), 1)
 
-        nodes = list(bayesian_network.nodes)
-        self._nodes = nodes
-        self._index = {node: i for i, node in enumerate(nodes)}
-        states, p_off, p_idx, c_off, c_idx = [], [0], [], [0], []
-        for node in nodes:
-            states.append(int(node.num_states))
-            p_idx.extend(self._index[q] for q in bayesian_network.parents_of(node))
-            p_off.append(len(p_idx))
-            c_idx.extend(self._index[q] for q in bayesian_network.children_of(node))
-            c_off.append(len(c_idx))
-        observed = [self._index[o] for o in self.observed_nodes]
-        self._cpt_shapes = [tuple(node.cpt.shape) for node in nodes]
+        pool = bayesian_network.__dict__.setdefault("_hip_plan_pool", {})
+        key = (tuple(id(o) for o in self.observed_nodes), self._n, self._dtype, str(self._device))
+        topo = pool.get(key)
+        if topo is None:
+            topo = pool[key] = _Topology(bayesian_network, self.observed_nodes)
+        self._topo = topo
+        self._nodes = topo.nodes
+        self._index = topo.index
+        self._cpt_shapes = topo.cpt_shapes
 
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(self._device):
-            _native.check(
-                self._lib.bn_plan_create(
-                    0 if self._dtype == torch.float32 else 1,
-                    self._n,
-                    len(nodes),
-                    _native.i32_array(states),
-                    _native.i32_array(p_off),
-                    _native.i32_array(p_idx),
-                    _native.i32_array(c_off),
-                    _native.i32_array(c_idx),
-                    _native.i32_array(observed),
-                    len(observed),
-                    ctypes.byref(handle),
+        if topo.idle:
+            self._owner = topo.idle.pop()
+            self._plan = self._owner.handle
+            with torch.cuda.device(self._device):
+                _native.check(self._lib.bn_reset_messages(self._plan, self._stream()))
+        else:
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(self._device):
+                _native.check(
+                    self._lib.bn_plan_create(
+                        0 if self._dtype == torch.float32 else 1,
+                        self._n,
+                        len(topo.nodes),
+                        _native.i32_array(topo.states),
+                        _native.i32_array(topo.p_off),
+                        _native.i32_array(topo.p_idx),
+                        _native.i32_array(topo.c_off),
+                        _native.i32_array(topo.c_idx),
+                        _native.i32_array(topo.observed),
+                        len(topo.observed),
+                        ctypes.byref(handle),
+                    )
                 )
-            )
-        self._plan = handle
+            self._owner = _PlanHandle(self._lib, handle)
+            self._plan = handle
+            if topo.is_tree is None:
+                is_tree, diameter = ctypes.c_int32(), ctypes.c_int32()
+                _native.check(self._lib.bn_plan_topology(self._plan, ctypes.byref(is_tree), ctypes.byref(diameter)))
+                topo.is_tree, topo.diameter = bool(is_tree.value), diameter.value
 
-        is_tree, diameter = ctypes.c_int32(), ctypes.c_int32()
-        _native.check(self._lib.bn_plan_topology(self._plan, ctypes.byref(is_tree), ctypes.byref(diameter)))
-        if is_tree.value:
-            self._num_iterations = settings.num_iterations if settings.num_iterations else diameter.value
+        if topo.is_tree:
+            self._num_iterations = settings.num_iterations if settings.num_iterations else topo.diameter
         else:
             if not settings.allow_loops:
                 raise ValueError("Network contains loops, but the specified settings disallow them.")
@@ -127,27 +206,30 @@ class HipSpaInferenceMachine(IInferenceMachine):
                 raise ValueError("Networks containers loops; number of iterations must be set explicitly.")
             self._num_iterations = settings.num_iterations
 
-        self.set_cpts([node.cpt for node in nodes])
+        self.set_cpts([node.cpt for node in self._nodes])
         self.factor_graph = _FactorGraphView(bayesian_network)
         self.must_iterate: bool = True
         self._evidence_keepalive = None
 
     def __del__(self):
-        plan = getattr(self, "_plan", None)
-        if plan:
-            try:
-                self._lib.bn_plan_destroy(plan)
-            except Exception:
-                pass
-            self._plan = None
+        owner = getattr(self, "_owner", None)
+        topo = getattr(self, "_topo", None)
+        if owner is not None and topo is not None and len(topo.idle) < _Topology.MAX_IDLE:
+            topo.idle.append(owner)
+        self._owner = None
+        self._plan = None
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
         return ctypes.c_void_p(_stream_handle(self._device))
 
     def set_cpts(self, cpts) -> None:
-        """Snapshot CPTs (one tensor per node, network order) into the plan."""
-        flat = torch.cat([c.detach().to(self._device, self._dtype).reshape(-1) for c in cpts])
+        """Snapshot CPTs into the plan: one tensor per node in network order, or one flat
+        tensor holding their concatenation."""
+        if isinstance(cpts, torch.Tensor):
+            flat = cpts.detach().to(self._device, self._dtype).contiguous().reshape(-1)
+        else:
+            flat = _flatten_cpts(cpts, self._device, self._dtype)
         if flat.numel() != self._lib.bn_plan_cpt_elements(self._plan):
             raise ValueError("CPT sizes do not match the network the machine was built for")
         with torch.cuda.device(self._device):
@@ -165,20 +247,31 @@ class HipSpaInferenceMachine(IInferenceMachine):
 
     # ------------------------------------------------------------------ interface
     def enter_evidence(self, evidence: Evidence) -> None:
-        tensors = [
-            t.detach().to(self._device, self._dtype).contiguous() for t in evidence.data
-        ]
-        if len(tensors) != len(self.observed_nodes):
-            raise ValueError("evidence must hold one tensor per observed node")
-        for t, node in zip(tensors, self.observed_nodes):
-            if tuple(t.shape) != (self._n, node.num_states):
-                raise RuntimeError(
-                    f"evidence for node {node} has shape {tuple(t.shape)}, expected {(self._n, node.num_states)}"
-                )
-        table = (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+        key = (self._device, self._dtype, self._n)
+        cached = getattr(evidence, "_hip_table", None)
+        if cached is None or cached[0] != key:
+            tensors = []
+            for t in evidence.data:
+                if t.device != self._device or t.dtype != self._dtype or not t.is_contiguous():
+                    t = t.detach().to(self._device, self._dtype).contiguous()
+                tensors.append(t)
+            if len(tensors) != len(self.observed_nodes):
+                raise ValueError("evidence must hold one tensor per observed node")
+            for t, node in zip(tensors, self.observed_nodes):
+                if tuple(t.shape) != (self._n, node.num_states):
+                    raise RuntimeError(
+                        f"evidence for node {node} has shape {tuple(t.shape)}, "
+                        f"expected {(self._n, node.num_states)}"
+                    )
+            table = (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+            cached = (key, tensors, table)
+            try:
+                evidence._hip_table = cached
+            except AttributeError:
+                pass
         with torch.cuda.device(self._device):
-            _native.check(self._lib.bn_enter_evidence(self._plan, table, self._stream()))
-        self._evidence_keepalive = tensors
+            _native.check(self._lib.bn_enter_evidence(self._plan, cached[2], self._stream()))
+        self._evidence_keepalive = cached
         self.must_iterate = True
 
     def _iterate(self) -> None:

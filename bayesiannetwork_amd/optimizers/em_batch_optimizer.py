@@ -1,0 +1,71 @@
+"""Mini-batch EM (reference: ``optimizers/em_batch_optimizer.py:15-84``): per batch a fresh
+machine, log-likelihood, expected counts, then
+``cpt <- (1-lr) * cpt + lr * ((1-gamma) * normalised_counts + gamma * uniform)``."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+from ..bayesian_network import BayesianNetwork
+from ..inference_machines.evidence import EvidenceLoader
+from .abstractions import IBatchOptimizer, IEvaluator
+from .common import MachineFactory, OptimizerLogger
+from .em_step import FlatModel, blend, expected_counts, normalise, reduce_statistics, regularise
+
+
+@dataclass(frozen=True)
+class EmBatchOptimizerSettings:
+    learning_rate: float
+    num_epochs: int
+    regularization: Optional[float] = None
+    sharded: bool = False  # all-reduce the statistics over torch.distributed ranks
+    # keep the per-step log-likelihood on the device and hand it to the logger at the end of
+    # each epoch, so that no EM step waits for the host (needs log_likelihood_tensor())
+    deferred_logging: bool = False
+
+
+class EmBatchOptimizer(IBatchOptimizer):
+    def __init__(self, bayesian_network: BayesianNetwork, inference_machine_factory: MachineFactory,
+                 settings: EmBatchOptimizerSettings, logger: Optional[OptimizerLogger] = None,
+                 evaluator: Optional[IEvaluator] = None):
+        self._network = bayesian_network
+        self._factory = inference_machine_factory
+        self._settings = settings
+        self._logger = logger
+        self._evaluator = evaluator
+
+    def optimize(self, evidence_loader: EvidenceLoader) -> None:
+        cfg = self._settings
+        flat_model = None
+        flat = None
+        for epoch in range(cfg.num_epochs):
+            pending = []
+            for iteration, evidence in enumerate(evidence_loader):
+                machine = self._factory(self._network)
+                machine.enter_evidence(evidence)
+                deferred = cfg.deferred_logging and hasattr(machine, "log_likelihood_tensor")
+                ll = machine.log_likelihood_tensor() if deferred else machine.log_likelihood()
+                if hasattr(machine, "expected_count_sums"):
+                    # whole-network M-step on one flat buffer; nodes get views of it
+                    if flat_model is None:
+                        flat_model = FlatModel(self._network)
+                    if flat is None or any(n.cpt._base is not flat for n in flat_model.nodes[:1]):
+                        flat = flat_model.gather()
+                    sums, ll, _ = reduce_statistics(machine, machine.expected_count_sums(), ll, cfg.sharded)
+                    flat = flat_model.m_step(sums, flat, cfg.learning_rate, cfg.regularization)
+                    flat_model.assign(flat)
+                else:
+                    counts, ll = expected_counts(machine, self._network, cfg.sharded, ll)
+                    for node, p in zip(self._network.nodes, counts):
+                        target = regularise(normalise(p), cfg.regularization)
+                        node.cpt = blend(node.cpt, target, cfg.learning_rate)
+                if deferred:
+                    pending.append((iteration, ll))
+                elif self._logger:
+                    self._logger.log(epoch, iteration, ll)
+                if self._evaluator:
+                    self._evaluator.evaluate(epoch, iteration, self._network)
+            if self._logger:
+                for iteration, ll in pending:
+                    self._logger.log(epoch, iteration, float(ll))

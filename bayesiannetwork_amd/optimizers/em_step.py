@@ -1,0 +1,158 @@
+"""E-step statistic and M-step arithmetic shared by both EM optimizers.
+
+E-step (reference ``em_optimizer.py:48-55``, ``em_batch_optimizer.py:61-68``):
+for every node the observation-mean of its family marginal.  A machine that
+offers ``expected_count_sums()`` (the HIP machine) hands back the *sums* in one
+flat float64 buffer without materialising any ``[N, ...]`` tensor; any other
+``IInferenceMachine`` is served through ``infer_nodes_with_parents``.
+
+When ``torch.distributed`` is initialised and ``sharded=True`` the statistic is
+all-reduced (SUM) over ranks together with the log-likelihood sum and the
+observation count — the single collective of a data-parallel EM step — so every
+rank then runs the identical M-step.
+
+M-step (``em_optimizer.py:57-63``, ``em_batch_optimizer.py:70-84``): normalise
+along the last axis; optionally blend with the uniform distribution
+(regularisation) and with the previous CPT (learning rate).
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ..bayesian_network import BayesianNetwork
+
+
+def expected_counts(machine, network: BayesianNetwork, sharded: bool = False,
+                    ll: Optional[float] = None) -> Tuple[List[torch.Tensor], Optional[float]]:
+    """Returns (per-node mean family marginals in network order, log-likelihood).
+
+    ``ll`` is passed through, and when ``sharded`` it is combined across ranks with the
+    machine's averaging convention (mean over all observations, or sum)."""
+    nodes = list(network.nodes)
+    dist = torch.distributed if sharded and torch.distributed.is_available() and torch.distributed.is_initialized() else None
+
+    if hasattr(machine, "expected_count_sums"):
+        flat = machine.expected_count_sums()
+        n_local = float(max(machine.num_observations, 1))
+        if dist is not None:
+            avg = machine.settings.average_log_likelihood
+            ll_sum = (ll * n_local) if (ll is not None and avg) else (ll if ll is not None else 0.0)
+            tail = torch.tensor([ll_sum, n_local], dtype=torch.float64, device=flat.device)
+            packed = torch.cat([flat, tail])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            flat, ll_total, n_total = packed[:-2], packed[-2].item(), packed[-1].item()
+            if ll is not None:
+                ll = ll_total / n_total if avg else ll_total
+            n_local = n_total
+        dtype = nodes[0].cpt.dtype
+        means = [(v / n_local).to(dtype) for v in machine.split_counts(flat)]
+        return means, ll
+
+    families = machine.infer_nodes_with_parents(nodes)
+    means = [p.mean(dim=0) for p in families]
+    if dist is not None:
+        n_local = float(families[0].shape[0])
+        sizes = [m.numel() for m in means]
+        flat = torch.cat([(m.double() * n_local).reshape(-1) for m in means])
+        avg = machine.settings.average_log_likelihood
+        ll_sum = (ll * n_local) if (ll is not None and avg) else (ll if ll is not None else 0.0)
+        packed = torch.cat([flat, torch.tensor([ll_sum, n_local], dtype=torch.float64, device=flat.device)])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        n_total = packed[-1].item()
+        if ll is not None:
+            ll = packed[-2].item() / n_total if avg else packed[-2].item()
+        pieces = torch.split(packed[:-2] / n_total, sizes)
+        means = [p.reshape(m.shape).to(m.dtype) for p, m in zip(pieces, means)]
+    return means, ll
+
+
+class FlatModel:
+    """All CPTs of a network as one flat device buffer plus the index vectors that let the
+    M-step run as a handful of whole-network tensor operations instead of a few per node
+    (785 nodes in the 784-leaf model).  Nodes keep CPT-shaped *views* of the buffer."""
+
+    def __init__(self, network: BayesianNetwork):
+        self.nodes = list(network.nodes)
+        first = self.nodes[0].cpt
+        self.device, self.dtype = first.device, first.dtype
+        self.shapes = [tuple(n.cpt.shape) for n in self.nodes]
+        self.sizes = [n.cpt.numel() for n in self.nodes]
+        rows, inv = [], []
+        row_base = 0
+        for shape, size in zip(self.shapes, self.sizes):
+            s_last = shape[-1]
+            n_rows = size // s_last
+            rows.append(torch.arange(row_base, row_base + n_rows).repeat_interleave(s_last))
+            inv.append(torch.full((size,), 1.0 / s_last, dtype=torch.float64))
+            row_base += n_rows
+        self.num_rows = row_base
+        self.row_ids = torch.cat(rows).to(self.device)
+        self.inv_states = torch.cat(inv).to(self.device)
+
+    def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        out, pos = [], 0
+        for shape, size in zip(self.shapes, self.sizes):
+            out.append(flat[pos : pos + size].view(shape))
+            pos += size
+        return out
+
+    def gather(self) -> torch.Tensor:
+        """Current CPTs as one flat tensor in the model dtype."""
+        return torch.cat([n.cpt.detach().to(self.device, self.dtype).reshape(-1) for n in self.nodes])
+
+    def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],
+               learning_rate: Optional[float], regularization: Optional[float]) -> torch.Tensor:
+        """count_sums: flat float64 expected counts (any positive scale).  Returns the new flat
+        CPT buffer in the model dtype."""
+        row_sums = torch.zeros(self.num_rows, dtype=torch.float64, device=self.device)
+        row_sums.index_add_(0, self.row_ids, count_sums)
+        cpt = count_sums / row_sums[self.row_ids]
+        if regularization:
+            cpt = (1 - regularization) * cpt + regularization * self.inv_states
+        if learning_rate is not None:
+            cpt = (1 - learning_rate) * old_flat.double() + learning_rate * cpt
+        return cpt.to(self.dtype)
+
+    def assign(self, flat: torch.Tensor) -> None:
+        for node, view in zip(self.nodes, self.views(flat)):
+            node.cpt = view
+
+
+def reduce_statistics(machine, flat_sums: torch.Tensor, ll, sharded: bool):
+    """All-reduce (SUM) of [expected-count sums, log-likelihood sum, observation count] over the
+    ranks of torch.distributed; identity when not sharded.  Returns (sums, ll, total N)."""
+    n_local = float(max(machine.num_observations, 1))
+    dist = torch.distributed
+    if not (sharded and dist.is_available() and dist.is_initialized()):
+        return flat_sums, ll, n_local
+    avg = machine.settings.average_log_likelihood
+    if isinstance(ll, torch.Tensor):
+        ll_sum = ll.reshape(1).double() * (n_local if avg else 1.0)
+    else:
+        ll_sum = torch.tensor([(ll * n_local) if avg else ll], dtype=torch.float64, device=flat_sums.device)
+    packed = torch.cat([flat_sums, ll_sum.to(flat_sums.device),
+                        torch.tensor([n_local], dtype=torch.float64, device=flat_sums.device)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    n_total = packed[-1]
+    ll_out = packed[-2] / n_total if avg else packed[-2]
+    if not isinstance(ll, torch.Tensor):
+        ll_out = ll_out.item()
+        n_total = n_total.item()
+    return packed[:-2], ll_out, n_total
+
+
+def normalise(p_conditional: torch.Tensor) -> torch.Tensor:
+    return p_conditional / p_conditional.sum(dim=-1, keepdim=True)
+
+
+def regularise(cpt: torch.Tensor, gamma: Optional[float]) -> torch.Tensor:
+    if not gamma:
+        return cpt
+    return (1 - gamma) * cpt + gamma / cpt.shape[-1]
+
+
+def blend(old: torch.Tensor, new: torch.Tensor, learning_rate: float) -> torch.Tensor:
+    return (1 - learning_rate) * old + learning_rate * new

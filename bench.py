@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EM steps per second on the MNIST-style 784-leaf latent model.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): Q(10) -> 784 x Y(2), random CPTs (seed 0), synthetic
+evidence x ~ Bernoulli(0.2) soft-clamped to [5e-7, 1-5e-7] (seed 1 + rank), float32.
+One step = one EM step of the mini-batch optimizer on one batch per GPU: fresh machine
+(pooled plan), enter_evidence, T=4 flooding iterations, log-likelihood, expected counts,
+[all-reduce of the counts over ranks], M-step (lr 0.1, regularisation 0.01).  Evidence is
+resident in HBM before the timed region.  Weak scaling: every rank gets its own batch of
+--batch observations; value = all ranks' observations / slowest rank's time.
+
+Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def build_model(ts, model: str, num_pixels: int = 784):
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+
+    gen = torch.Generator().manual_seed(0)
+
+    def rand_cpt(shape):
+        p = torch.rand(shape, generator=gen, dtype=torch.float64)
+        p = (p / p.sum(dim=-1, keepdim=True)).to(ts.dtype)
+        return (p / p.sum(dim=-1, keepdim=True)).to(ts.device)
+
+    q = Node(torch.full((10,), 0.1, dtype=ts.dtype, device=ts.device), name="Q")
+    builder = BayesianNetworkBuilder().add_node(q)
+    ys = []
+    if model == "c3b":
+        f1 = Node(rand_cpt((10, 2)), name="F1")
+        f2 = Node(rand_cpt((10, 2)), name="F2")
+        builder.add_node(f1, parents=q).add_node(f2, parents=q)
+        for i in range(num_pixels):
+            y = Node(rand_cpt((2, 2, 2)), name=f"Y{i}")
+            builder.add_node(y, parents=[f1, f2])
+            ys.append(y)
+    else:
+        for i in range(num_pixels):
+            y = Node(rand_cpt((10, 2)), name=f"Y{i}")
+            builder.add_node(y, parents=q)
+            ys.append(y)
+    return builder.build(), ys
+
+
+def synthetic_evidence(ts, n, num_pixels, seed, device):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.rand((num_pixels, n), generator=gen) < 0.2).to(ts.dtype) * 0.999999 + 5e-7
+    x = x.to(device)
+    stacked = torch.stack([1 - x, x], dim=2).contiguous()  # [pixels, n, 2]
+    return Evidence(list(stacked.unbind(0)), ts)
+
+
+class _Batches:
+    def __init__(self, batches, total):
+        self._batches, self.num_observations = batches, total
+
+    def __len__(self):
+        return len(self._batches)
+
+    def __iter__(self):
+        return iter(self._batches)
+
+
+def cpu_baseline(model: str, n: int, steps: int, iters):
+    """The CPU oracle (torch-on-CPU restatement of the reference's pass structure) doing the
+    same EM step on a bounded sample.  kind = "port"."""
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+    from oracle.spa_oracle import SpaOracle, m_step_batch
+
+    ts = TorchSettings(device="cpu", dtype="float32")
+    network, ys = build_model(ts, model)
+    ev = synthetic_evidence(ts, n, len(ys), 1, "cpu").data
+    cpts = [node.cpt for node in network.nodes]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle = SpaOracle(network, ys, n, dtype=torch.float32, num_iterations=iters, allow_loops=True, cpts=cpts)
+        oracle.enter_evidence(ev)
+        oracle.log_likelihood(True)
+        cpts = m_step_batch(cpts, oracle.expected_counts(), 0.1, 0.01)
+    dt = time.perf_counter() - t0
+    return dict(value=n * steps / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} EM steps x {n} observations, float32, torch CPU oracle")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=60000, help="observations per GPU per step")
+    ap.add_argument("--model", choices=["c3a", "c3b"], default="c3a")
+    ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from bayesiannetwork_amd.inference_machines.hip_spa import (
+        HipSpaInferenceMachine,
+        SpaInferenceMachineSettings,
+        enable_profiling,
+        profile_report,
+    )
+    from bayesiannetwork_amd.optimizers import EmBatchOptimizer, EmBatchOptimizerSettings, OptimizerLogger
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype=args.dtype)
+    device = torch.device("cuda", local_rank)
+    network, ys = build_model(ts, args.model)
+    iters = 10 if args.model == "c3b" else None
+    n = args.batch
+    # two distinct resident batches, alternated, so no step re-reads the evidence it just used
+    batches = [synthetic_evidence(ts, n, len(ys), 1 + 17 * rank + b, device) for b in range(2)]
+
+    def factory(net):
+        return HipSpaInferenceMachine(
+            SpaInferenceMachineSettings(ts, True, num_iterations=iters, allow_loops=args.model == "c3b"),
+            net, ys, n)
+
+    logger = OptimizerLogger()
+
+    def run(steps):
+        opt = EmBatchOptimizer(
+            network, factory,
+            EmBatchOptimizerSettings(learning_rate=0.1, num_epochs=1, regularization=0.01,
+                                     sharded=world > 1, deferred_logging=True),
+            logger)
+        opt.optimize(_Batches([batches[i % 2] for i in range(steps)], n * steps))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    if not args.no_kernel_timing:
+        enable_profiling(True)
+        profile_report()
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    kernels = []
+    if not args.no_kernel_timing:
+        kernels = profile_report()
+        enable_profiling(False)
+
+    if rank == 0:
+        machine = factory(network)
+        t_used = machine.num_iterations
+        lls = [log.ll for log in logger.logs]
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda k: k["total_ms"])
+            avg_s = dom["total_ms"] / dom["launches"] / 1e3
+            achieved = dom["alg_bytes"] / avg_s / 1e9
+            roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_s * 1e3,
+                            alg_bytes_per_launch=dom["alg_bytes"])
+        out = {
+            "metric": "evidence samples/sec (sum-product infer + EM step), MNIST 784-leaf latent model",
+            "value": world * n * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "float32" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("Q(10)->784xY(2) latent-class model" if args.model == "c3a"
+                             else "Q(10)->F1,F2(2)->784xY(2|F1,F2) loopy model")
+                + f", EM step (T={t_used} flooding iterations + ll + expected counts + M-step)",
+                "batch_per_gpu": n,
+                "global_batch": n * world,
+                "learning_rate": 0.1,
+                "regularization": 0.01,
+                "parallelism": f"observations sharded over {world} GPU(s), counts all-reduced" if world > 1 else "single GPU",
+            },
+            "ll_first_last": [lls[args.warmup], lls[-1]] if len(lls) > args.warmup else None,
+            "roofline": roofline,
+            "kernels": [
+                dict(kernel=k["kernel"], launches=k["launches"], avg_ms=k["total_ms"] / k["launches"],
+                     alg_GBps=(k["alg_bytes"] / (k["total_ms"] / k["launches"] / 1e3) / 1e9) if k["total_ms"] > 0 else None)
+                for k in kernels
+            ],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, 2000, 3, iters)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,6 +163,19 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream);
 int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction, void* out_dev,
                    void* stream);
 
+/*
+ * Per-kernel timing for benchmarks (process-wide switch): while enabled, every kernel any
+ * plan launches is bracketed by hipEvents recorded on the launch stream.
+ * bn_profile_report waits for the recorded events, writes a JSON array
+ *   [{"kernel": "...", "launches": n, "total_ms": x, "alg_bytes": b}, ...]
+ * (NUL-terminated; "[]" if it does not fit) and clears the records.  alg_bytes is the
+ * compulsory traffic of ONE launch: every live input message read once and every used
+ * output written once, CPT traffic ignored.  No counterpart in the reference (it has no
+ * profiling hooks).
+ */
+int bn_profile_enable(int32_t enabled);
+int bn_profile_report(char* buffer, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

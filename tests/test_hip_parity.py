@@ -104,11 +104,7 @@ def test_machine_matches_reference(name):
         rtol = 1e-10 if fx.dtype == torch.float64 else 1e-5
         np.testing.assert_allclose(ll_sum, float(fx[f"{want}/ll_sum"]), rtol=rtol)
         np.testing.assert_allclose(ll_avg, float(fx[f"{want}/ll_avg"]), rtol=rtol)
-        c = torch.stack([machine.local_log_likelihoods(n) for n in nodes])
-        got_c = c.cpu().numpy()
-        exp_c = fx[f"{want}/c"]
-        # normalisers are compared absolutely as well: individual c can be ~0 while ll is O(100)
-        np.testing.assert_allclose(got_c, exp_c, rtol=rtol, atol=(1e-10 if fx.dtype == torch.float64 else 2e-5))
+        _close(torch.stack([machine.local_log_likelihoods(n) for n in nodes]), fx, "c")
     for key in fx.keys("out/f2v/") + fx.keys("out/v2f/"):
         _, kind, var, owner = key.split("/")
         got = machine.message(by_name[var], by_name[owner], kind)
