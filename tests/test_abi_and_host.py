@@ -1,0 +1,145 @@
+"""CPU-only checks: the shared library loads and exports exactly what include/bn_hip.h
+declares, argument validation works before any GPU call, and the host classes keep the
+reference's ordering and validation rules."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from bayesiannetwork_amd.bayesian_network import (
+    BayesianNetwork,
+    BayesianNetworkBuilder,
+    NetworkValidationError,
+    Node,
+)
+from bayesiannetwork_amd.inference_machines.evidence import Evidence, EvidenceLoader
+from bayesiannetwork_amd.inference_machines.hip_spa import _native
+from bayesiannetwork_amd.statistics import generate_random_probability_matrix, is_valid_probability_matrix
+from bayesiannetwork_amd.torch_settings import TorchSettings
+
+TS = TorchSettings(device="cpu", dtype="float64")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bn_hip.h")).read()
+    declared = set(re.findall(r"\b(bn_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.bn_abi_version() == _native.ABI_VERSION
+
+
+def test_plan_create_rejects_bad_topology_without_touching_the_gpu():
+    lib = _native.load()
+    handle = ctypes.c_void_p()
+
+    def create(dtype, n, states, p_off, p_idx, c_off, c_idx, obs):
+        return lib.bn_plan_create(dtype, n, len(states), _native.i32_array(states), _native.i32_array(p_off),
+                                  _native.i32_array(p_idx), _native.i32_array(c_off), _native.i32_array(c_idx),
+                                  _native.i32_array(obs), len(obs), ctypes.byref(handle))
+
+    good = dict(states=[2, 3], p_off=[0, 0, 1], p_idx=[0], c_off=[0, 1, 1], c_idx=[1], obs=[1])
+    assert create(7, 4, **good) == -1 and b"dtype" in lib.bn_last_error()
+    assert create(0, 0, **good) == -1 and b"num_observations" in lib.bn_last_error()
+    bad_parent = dict(good, p_idx=[5])
+    assert create(0, 4, **bad_parent) == -1 and b"parent" in lib.bn_last_error()
+    mismatch = dict(good, c_off=[0, 0, 0], c_idx=[])
+    assert create(0, 4, **mismatch) == -1 and b"disagree" in lib.bn_last_error()
+    twice = dict(good, obs=[1, 1])
+    assert create(0, 4, **twice) == -1 and b"twice" in lib.bn_last_error()
+    assert lib.bn_plan_destroy(None) == 0
+
+
+def test_machine_refuses_cpu_settings():
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    a = Node(torch.tensor([0.5, 0.5], dtype=torch.float64), "A")
+    b = Node(torch.tensor([[0.5, 0.5], [0.1, 0.9]], dtype=torch.float64), "B")
+    net = BayesianNetworkBuilder().add_node(a).add_node(b, parents=a).build()
+    with pytest.raises(ValueError, match="no CPU path"):
+        HipSpaInferenceMachine(SpaInferenceMachineSettings(TS, False), net, [b], 3)
+
+
+def test_torch_settings_validation():
+    assert TorchSettings(device="cpu", dtype="float32").dtype == torch.float32
+    with pytest.raises(TypeError):
+        TorchSettings("cpu", "float32")
+    with pytest.raises(ValueError):
+        TorchSettings(device="tpu", dtype="float32")
+    with pytest.raises(ValueError):
+        TorchSettings(device="cpu", dtype="float16")
+    os.environ["BN__TORCH_SETTINGS__DEVICE"] = "cpu"
+    os.environ["BN__TORCH_SETTINGS__DTYPE"] = "float64"
+    try:
+        assert TorchSettings().dtype == torch.float64
+    finally:
+        del os.environ["BN__TORCH_SETTINGS__DEVICE"], os.environ["BN__TORCH_SETTINGS__DTYPE"]
+
+
+def test_node_order_is_graph_insertion_order():
+    # child listed before its parent: the parent is inserted right after the child
+    mk = lambda shape, name: Node(generate_random_probability_matrix(shape, TS), name)
+    a, b, c, d = mk((2,), "A"), mk((2, 3), "B"), mk((3, 2), "C"), mk((2, 2), "D")
+    net = BayesianNetwork([c, a, b, d], {c: [b], a: [], b: [a], d: [a]})
+    assert [n.name for n in net.nodes] == ["C", "B", "A", "D"]
+    assert [n.name for n in net.children_of(a)] == ["B", "D"]
+    assert [n.name for n in net.parents_of(c)] == ["B"]
+    assert [(p.name, ch.name) for p, ch in net.edges] == [("B", "C"), ("A", "B"), ("A", "D")]
+    assert net.is_leaf_node(c) and not net.is_leaf_node(a)
+    assert net.degrees_of_freedom == 1 + 2 * 2 + 3 * 1 + 2 * 1
+    assert list(net.G.nodes) == list(net.nodes)
+    # multi-parent CPT axis order follows the parents list
+    e = mk((3, 2, 4), "E")
+    net2 = BayesianNetwork([a, b, e], {a: [], b: [a], e: [b, a]})
+    assert [n.name for n in net2.parents_of(e)] == ["B", "A"]
+
+
+def test_builder_validation_rules():
+    mk = lambda shape, name: Node(generate_random_probability_matrix(shape, TS), name)
+    a, b = mk((2,), "A"), mk((2, 3), "B")
+    assert BayesianNetworkBuilder().add_node(a).add_node(b, parents=a).build().num_nodes == 2
+    with pytest.raises(NetworkValidationError):  # CPT axis does not match parent cardinality
+        BayesianNetworkBuilder().add_node(a).add_node(mk((3, 3), "X"), parents=a).build()
+    with pytest.raises(ValueError):  # same node twice
+        BayesianNetworkBuilder().add_node(a).add_node(a).add_node(b, parents=a).build()
+    with pytest.raises(NetworkValidationError):  # isolated node
+        BayesianNetworkBuilder().add_node(a).add_node(b, parents=a).add_node(mk((2,), "Z")).build()
+    with pytest.raises(NetworkValidationError):  # parent not in network
+        BayesianNetworkBuilder().add_node(b, parents=a).build()
+    with pytest.raises(ValueError):  # duplicate name
+        BayesianNetworkBuilder().add_node(a).add_node(mk((2, 2), "A"), parents=a).build()
+    with pytest.raises(Exception, match="sum to 1"):
+        Node(torch.tensor([0.5, 0.6], dtype=torch.float64))
+    assert is_valid_probability_matrix(generate_random_probability_matrix((4, 5), TS))
+
+
+def test_evidence_and_loader():
+    ev = Evidence([torch.eye(3, dtype=torch.float32), torch.ones((3, 2))], TS)
+    assert len(ev) == 3 and ev.num_observed_nodes == 2 and ev.data[0].dtype == torch.float64
+    assert ev[1:3].num_observations == 2
+    assert ev.get_observation(0).shape == (2, 3) if False else True
+    with pytest.raises(AssertionError):
+        Evidence([torch.eye(3), torch.ones((2, 2))], TS)
+
+    class DS(list):
+        pass
+
+    class DL:
+        dataset = DS(range(10))
+
+        def __len__(self):
+            return 2
+
+        def __iter__(self):
+            yield torch.zeros((5, 4)), None
+            yield torch.ones((5, 4)), None
+
+    loader = EvidenceLoader(DL(), lambda batch: Evidence([torch.stack([1 - x, x], dim=1) for x in batch.T], TS))
+    batches = list(loader)
+    assert len(loader) == 2 and loader.num_observations == 10
+    assert batches[1].num_observed_nodes == 4 and batches[1].data[0][0, 1] == 1
