@@ -13,7 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "kernels_fast.h"
+#include "dispatch_fast.h"
 #include "kernels_generic.h"
 #include "plan.h"
 
@@ -182,16 +182,26 @@ int fill_arrays(bn::Plan& p, int64_t first_array, int64_t count, hipStream_t s) 
 template <typename T>
 int reset_messages_t(bn::Plan& p, hipStream_t s) {
   T* arena = static_cast<T*>(p.arena);
-  int rc = fill_arrays<T>(p, p.fill_messages, p.fill_count - p.fill_messages, s);
-  if (rc != BN_OK) return rc;
+  p.obs_pending = p.fill_count > p.fill_messages;
   const int64_t c_elems = (int64_t)p.n_nodes * p.npad;
   BN_HIP_CHECK(hipMemsetAsync(arena + p.c_base, 0, c_elems * sizeof(T), s));
   p.fresh = true;
+  bn::invalidate_fast(p);
   return BN_OK;
+}
+
+// Observation slots that were reset but never received evidence get their uniform value now.
+int settle_observations(bn::Plan& p, hipStream_t s) {
+  if (!p.obs_pending) return BN_OK;
+  int rc = p.dtype == BN_F32 ? fill_arrays<float>(p, p.fill_messages, p.fill_count - p.fill_messages, s)
+                             : fill_arrays<double>(p, p.fill_messages, p.fill_count - p.fill_messages, s);
+  if (rc == BN_OK) p.obs_pending = false;
+  return rc;
 }
 
 // Anything that reads message arrays directly needs them to hold real values.
 int materialize(bn::Plan& p, hipStream_t s) {
+  if (int rc = settle_observations(p, s)) return rc;
   if (!p.fresh) return BN_OK;
   int rc = p.dtype == BN_F32 ? fill_arrays<float>(p, 0, p.fill_messages, s)
                              : fill_arrays<double>(p, 0, p.fill_messages, s);
@@ -208,7 +218,12 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
     const int32_t fresh = p.fresh ? 1 : 0;
     for (auto& g : p.vgroups) {
       const int32_t K = (int32_t)g.nodes.size();
-      prof_begin(vlabel(g), variable_bytes(p, g), s);
+      {
+        std::string label = vlabel(g);
+        double bytes = variable_bytes(p, g);
+        bn::variable_profile(p, (size_t)(&g - p.vgroups.data()), label, bytes);
+        prof_begin(label, bytes, s);
+      }
       int rc = bn::launch_variable_fast<T>(p, g, arena, fresh, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised variable kernel failed");
       if (rc == 0) {
@@ -226,8 +241,13 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
     p.fresh = false;  // every variable -> factor message has been written; the factor pass writes the rest
     for (auto& g : p.fgroups) {
       const int32_t K = (int32_t)g.nodes.size();
-      prof_begin(flabel("factor_pass", g), factor_bytes(p, g, false), s);
-      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, s);
+      {
+        std::string label = flabel("factor_pass", g);
+        double bytes = factor_bytes(p, g, false);
+        bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
+        prof_begin(label, bytes, s);
+      }
+      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == iterations - 1 ? 1 : 0, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
       if (rc == 0) {
         bn::FactorDims fd = make_dims(g.dims);
@@ -475,6 +495,7 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
     }
     BN_LAUNCH_CHECK("evidence_scatter");
   }
+  p.obs_pending = false;
   prof_end(s);
   return BN_OK;
 }
@@ -485,6 +506,7 @@ int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
   bn::Plan& p = plan->p;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = settle_observations(p, s)) return rc;
   return p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, s) : iterate_t<double>(p, num_iterations, s);
 }
 
@@ -546,6 +568,7 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
   if (owner < 0 || owner >= p.n_nodes) return fail(BN_ERR_INVALID, "owner out of range");
   if (slot == -2) {
     if (p.observed_slot_of[owner] < 0) return fail(BN_ERR_INVALID, "node is not observed");
+    if (int rc = settle_observations(p, static_cast<hipStream_t>(stream))) return rc;
     return gather(p, p.obs_off[p.observed_slot_of[owner]], -1, p.states[owner], out_dev,
                   static_cast<hipStream_t>(stream));
   }

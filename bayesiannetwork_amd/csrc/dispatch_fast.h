@@ -1,0 +1,431 @@
+// Host side of the specialised float32 path: which groups get which kernel, the scratch
+// the wide / fused kernels need, and the launches.  Each launch_* helper returns 1 if it
+// handled the group, 0 if the caller must use the generic kernel, and a negative value on
+// a launch failure.
+#pragma once
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fast.h"
+#include "kernels_wide.h"
+#include "plan.h"
+
+namespace bn {
+
+constexpr int32_t kMaxUncovered = 8;
+constexpr int32_t kLeafVec = 2;  // observations per lane in the leaf-family kernel (register budget)
+
+struct WideNode {
+  int32_t node = -1, vgroup = -1, vpos = -1;
+  int32_t S = 0, I = 0;
+  int32_t fused_fgroup = -1;  // factor group whose leaf-family kernel maintains the partials, or -1
+  int32_t chunks = 0, chunk_len = 0;
+  std::vector<int32_t> covered, uncovered;
+  int32_t* d_covered = nullptr;
+  int32_t* d_uncovered = nullptr;
+  double* part_mant = nullptr;
+  int32_t* part_exp = nullptr;
+  double* scaled = nullptr;
+  bool partials_valid = false;
+};
+
+struct FusedFamily {
+  int32_t wide_index = -1;
+  int64_t* d_obs_off = nullptr;
+  int64_t* d_c_off = nullptr;
+};
+
+struct FastState {
+  std::vector<WideNode> wide;
+  std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
+  std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
+  std::vector<char> vgroup_skip;              // variable groups whose every node a fused kernel serves
+};
+
+inline std::map<const Plan*, FastState>& fast_states() {
+  static std::map<const Plan*, FastState> states;
+  return states;
+}
+
+inline FastState* fast_state(const Plan& p) {
+  auto it = fast_states().find(&p);
+  return it == fast_states().end() ? nullptr : &it->second;
+}
+
+inline bool small_dim(int32_t d) {
+  switch (d) {
+#define X(V) \
+  case V:    \
+    return true;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return false;
+}
+
+inline bool is_wide_group(const Plan& p, const VariableGroup& g) {
+  return p.dtype == 0 && g.num_inputs > kWideFanIn && small_dim(g.num_states);
+}
+
+inline int64_t fast_scratch_elems(const Plan&) { return 0; }
+
+template <typename U>
+inline bool dev_upload(const std::vector<U>& host, U** dev, int64_t& bytes) {
+  *dev = nullptr;
+  if (host.empty()) return true;
+  if (hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(U)) != hipSuccess) return false;
+  bytes += (int64_t)(host.size() * sizeof(U));
+  return hipMemcpy(*dev, host.data(), host.size() * sizeof(U), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+inline void release_fast(Plan& p) {
+  FastState* st = fast_state(p);
+  if (!st) return;
+  for (auto& w : st->wide) {
+    if (w.d_covered) (void)hipFree(w.d_covered);
+    if (w.d_uncovered) (void)hipFree(w.d_uncovered);
+    if (w.part_mant) (void)hipFree(w.part_mant);
+    if (w.part_exp) (void)hipFree(w.part_exp);
+    if (w.scaled) (void)hipFree(w.scaled);
+  }
+  for (auto& kv : st->fused) {
+    if (kv.second.d_obs_off) (void)hipFree(kv.second.d_obs_off);
+    if (kv.second.d_c_off) (void)hipFree(kv.second.d_c_off);
+  }
+  fast_states().erase(&p);
+}
+
+inline void invalidate_fast(Plan& p) {
+  if (FastState* st = fast_state(p))
+    for (auto& w : st->wide) w.partials_valid = false;
+}
+
+inline int prepare_fast(Plan& p) {
+  FastState st;
+  st.vgroup_skip.assign(p.vgroups.size(), 0);
+  if (p.dtype != 0) {
+    fast_states()[&p] = std::move(st);
+    return 0;
+  }
+  // wide variable nodes
+  for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
+    const VariableGroup& g = p.vgroups[gi];
+    if (!is_wide_group(p, g)) continue;
+    for (size_t k = 0; k < g.nodes.size(); ++k) {
+      WideNode w;
+      w.node = g.nodes[k];
+      w.vgroup = (int32_t)gi;
+      w.vpos = (int32_t)k;
+      w.S = g.num_states;
+      w.I = g.num_inputs;
+      st.wide_of_node[w.node] = (int32_t)st.wide.size();
+      st.wide.push_back(std::move(w));
+    }
+  }
+  // leaf families around a wide parent
+  std::vector<char> handled(p.n_nodes, 0);
+  for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
+    const FactorGroup& g = p.fgroups[fi];
+    if (g.dims.size() != 2 || !small_dim(g.dims[0]) || !small_dim(g.dims[1])) continue;
+    const int32_t parent = p.parents[g.nodes[0]][0];
+    auto wit = st.wide_of_node.find(parent);
+    if (wit == st.wide_of_node.end()) continue;
+    WideNode& w = st.wide[wit->second];
+    if (w.fused_fgroup >= 0) continue;
+    bool ok = g.nodes.size() >= 16;
+    for (int32_t j : g.nodes) ok = ok && p.parents[j][0] == parent && p.children[j].empty();
+    if (!ok || w.I - (int32_t)g.nodes.size() > kMaxUncovered) continue;
+    // covered slots of the parent, in the factor group's node order
+    std::vector<char> is_covered(w.I, 0);
+    for (int32_t j : g.nodes) {
+      const auto& ch = p.children[parent];
+      const int32_t slot = (int32_t)(std::find(ch.begin(), ch.end(), j) - ch.begin());
+      w.covered.push_back(slot);
+      is_covered[slot] = 1;
+    }
+    for (int32_t i = 0; i < w.I; ++i)
+      if (!is_covered[i]) w.uncovered.push_back(i);
+    w.fused_fgroup = (int32_t)fi;
+    FusedFamily fam;
+    fam.wide_index = wit->second;
+    std::vector<int64_t> obs, cs;
+    for (int32_t j : g.nodes) {
+      obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : -1);
+      cs.push_back(p.c_off[j]);
+      handled[j] = 1;
+    }
+    if (!dev_upload(obs, &fam.d_obs_off, p.device_bytes) || !dev_upload(cs, &fam.d_c_off, p.device_bytes)) return -2;
+    st.fused[(int32_t)fi] = fam;
+  }
+  for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
+    bool all = true;
+    for (int32_t j : p.vgroups[gi].nodes) all = all && handled[j];
+    st.vgroup_skip[gi] = all ? 1 : 0;
+  }
+  // chunk geometry + scratch
+  for (auto& w : st.wide) {
+    if (w.fused_fgroup < 0) {
+      for (int32_t i = 0; i < w.I - 2; ++i) w.covered.push_back(i);
+      w.uncovered = {w.I - 2, w.I - 1};
+    }
+    const int32_t n = (int32_t)w.covered.size();
+    const int64_t want = (4096 + p.ntiles - 1) / p.ntiles;
+    int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
+    w.chunk_len = (n + chunks - 1) / chunks;
+    w.chunks = (n + w.chunk_len - 1) / w.chunk_len;
+    if (!dev_upload(w.covered, &w.d_covered, p.device_bytes) || !dev_upload(w.uncovered, &w.d_uncovered, p.device_bytes))
+      return -2;
+    const size_t rows = (size_t)w.chunks * w.S * p.npad;
+    if (hipMalloc(reinterpret_cast<void**>(&w.part_mant), rows * sizeof(double)) != hipSuccess) return -2;
+    if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), rows * sizeof(int32_t)) != hipSuccess) return -2;
+    if (hipMalloc(reinterpret_cast<void**>(&w.scaled), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
+    p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 8);
+  }
+  fast_states()[&p] = std::move(st);
+  return 0;
+}
+
+inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode& w, int32_t fresh) {
+  WideArgs a;
+  a.in_off = g.d_in + (size_t)w.vpos * g.num_inputs;
+  a.out_off = g.d_out + (size_t)w.vpos * g.num_inputs;
+  a.c_off = g.c_off[w.vpos];
+  a.I = w.I;
+  a.chunks = w.chunks;
+  a.chunk_len = w.chunk_len;
+  a.n_covered = (int32_t)w.covered.size();
+  a.covered = w.d_covered;
+  a.uncovered = w.d_uncovered;
+  a.n_uncovered = (int32_t)w.uncovered.size();
+  a.part_mant = w.part_mant;
+  a.part_exp = w.part_exp;
+  a.scaled = w.scaled;
+  a.npad = p.npad;
+  a.ntiles = p.ntiles;
+  a.fresh = fresh;
+  return a;
+}
+
+template <int S>
+inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, float* arena, int32_t fresh,
+                             hipStream_t s) {
+  const WideArgs a = wide_args(p, g, w, fresh);
+  const bool fused = w.fused_fgroup >= 0;
+  if (!fused || !w.partials_valid) {
+    hipLaunchKernelGGL(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+    if (!launch_ok()) return false;
+  }
+  hipLaunchKernelGGL(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles)), dim3(256), 0, s, arena, a);
+  if (!launch_ok()) return false;
+  if (!fused) {
+    hipLaunchKernelGGL(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+    if (!launch_ok()) return false;
+  }
+  return true;
+}
+
+// Label and compulsory bytes of the variable-pass launch for group gi when a special path
+// serves it (profiling only).  Returns false when the defaults apply.
+inline bool variable_profile(const Plan& p, size_t gi, std::string& label, double& bytes) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0) return false;
+  const VariableGroup& g = p.vgroups[gi];
+  if (st->vgroup_skip[gi]) {
+    label = "variable_pass(fused into leaf_family)[I=" + std::to_string(g.num_inputs) + ",S=" +
+            std::to_string(g.num_states) + "]";
+    bytes = 0;
+    return true;
+  }
+  if (!is_wide_group(p, g)) return false;
+  bool any_fused = false;
+  double fused_bytes = 0;
+  for (int32_t j : g.nodes) {
+    const WideNode& w = st->wide[st->wide_of_node[j]];
+    if (w.fused_fgroup < 0) continue;
+    any_fused = true;
+    // inputs + outputs of the covered slots are moved by the leaf-family kernel
+    fused_bytes += 2.0 * w.S * (double)w.covered.size() * (double)p.N * (double)p.elem_size;
+  }
+  if (!any_fused) return false;
+  label = "wide_combine[I=" + std::to_string(g.num_inputs) + ",S=" + std::to_string(g.num_states) + "]";
+  bytes -= fused_bytes;
+  return true;
+}
+
+inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double& bytes) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0) return false;
+  auto it = st->fused.find((int32_t)fi);
+  if (it == st->fused.end()) return false;
+  const FactorGroup& g = p.fgroups[fi];
+  const WideNode& w = st->wide[it->second.wide_index];
+  // the factor pass itself + the covered part of the wide parent's variable pass + the leaf
+  // variables' whole variable pass (inputs observation + factor message, outputs message + c)
+  double leaf = 0;
+  for (int32_t j : g.nodes) {
+    const int32_t fan_in = 1 + (p.observed_slot_of[j] >= 0 ? 1 : 0);
+    leaf += (double)p.states[j] * fan_in + (double)p.states[j] + 1;
+  }
+  bytes += 2.0 * w.S * (double)w.covered.size() * (double)p.N * (double)p.elem_size +
+           leaf * (double)p.N * (double)p.elem_size;
+  label = "leaf_family[" + std::to_string(g.dims[0]) + "x" + std::to_string(g.dims[1]) +
+          ",K=" + std::to_string(g.nodes.size()) + "]";
+  return true;
+}
+
+template <typename T>
+int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, hipStream_t s) {
+  if constexpr (!std::is_same<T, float>::value) {
+    return 0;
+  } else {
+    float* arena = arena_t;
+    FastState* st = fast_state(p);
+    const size_t gi = (size_t)(&g - p.vgroups.data());
+    const int32_t K = (int32_t)g.nodes.size();
+    if (st && st->vgroup_skip[gi]) return 1;  // done inside the leaf-family kernel
+    if (st && is_wide_group(p, g)) {
+      for (int32_t j : g.nodes) {
+        WideNode& w = st->wide[st->wide_of_node[j]];
+        bool ok = false;
+        switch (g.num_states) {
+#define X(SV)                                                \
+  case SV:                                                   \
+    ok = launch_wide_node<SV>(p, g, w, arena, fresh, s);     \
+    break;
+          BN_SMALL_DIMS(X)
+#undef X
+        }
+        if (!ok) return -1;
+      }
+      return 1;
+    }
+    if (g.num_inputs * g.num_states > 12) return 0;  // per-lane state would not fit the register budget
+    VarSmallFn fn = var_small_lookup(g.num_inputs, g.num_states);
+    if (!fn) return 0;
+    hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K,
+                       p.ntiles, fresh);
+    return launch_ok() ? 1 : -1;
+  }
+}
+
+using LeafFamilyFn = void (*)(float*, const float*, LeafFamilyArgs);
+
+template <int D0>
+inline LeafFamilyFn leaf_family_for_s(int32_t s) {
+  switch (s) {
+#define X(SV) \
+  case SV:    \
+    return leaf_family_p1<D0, SV, kLeafVec>;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_family_for_s<DV>(s);
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+template <typename T>
+int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t last_iteration,
+                       hipStream_t s) {
+  if constexpr (!std::is_same<T, float>::value) {
+    return 0;
+  } else {
+    float* arena = arena_t;
+    const float* cpts = cpts_t;
+    const int32_t K = (int32_t)g.nodes.size();
+    const uint32_t blocks = wave_blocks((int64_t)K * p.ntiles);
+    FastState* st = fast_state(p);
+    const size_t fi = (size_t)(&g - p.fgroups.data());
+    if (st) {
+      auto it = st->fused.find((int32_t)fi);
+      if (it != st->fused.end()) {
+        WideNode& w = st->wide[it->second.wide_index];
+        LeafFamilyFn fn = leaf_family_lookup(g.dims[0], g.dims[1]);
+        if (!fn) return -1;
+        LeafFamilyArgs a;
+        a.f_in = g.d_in;
+        a.f_out = g.d_out;
+        a.cpt_off = g.d_cpt;
+        a.obs_off = it->second.d_obs_off;
+        a.c_off = it->second.d_c_off;
+        a.K = K;
+        a.chunks = w.chunks;
+        a.chunk_len = w.chunk_len;
+        a.part_mant = w.part_mant;
+        a.part_exp = w.part_exp;
+        a.scaled = w.scaled;
+        a.npad = p.npad;
+        a.ntiles = p.ntiles;
+        a.fresh = fresh;
+        a.store_v2f = last_iteration;
+        hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts,
+                           a);
+        if (!launch_ok()) return -1;
+        w.partials_valid = true;
+        return 1;
+      }
+    }
+    if (g.dims.size() == 1) {
+      hipLaunchKernelGGL(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
+                         p.ntiles);
+      return launch_ok() ? 1 : -1;
+    }
+    if (g.dims.size() == 2) {
+      FactorP1Fn fn = factor_p1_lookup(g.dims[0], g.dims[1]);
+      if (!fn) return 0;
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+      return launch_ok() ? 1 : -1;
+    }
+    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
+      hipLaunchKernelGGL((factor_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt,
+                         K, p.ntiles);
+      return launch_ok() ? 1 : -1;
+    }
+    return 0;
+  }
+}
+
+template <typename T>
+int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, double* partial, hipStream_t s) {
+  if constexpr (!std::is_same<T, float>::value) {
+    return 0;
+  } else {
+    const float* arena = arena_t;
+    const int32_t K = (int32_t)g.nodes.size();
+    const uint32_t blocks = wave_blocks((int64_t)K * nchunks);
+    if (g.dims.size() == 1) {
+      EmP1Fn fn = em_root_lookup(g.dims[0]);
+      if (!fn) return 0;
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
+      return launch_ok() ? 1 : -1;
+    }
+    if (g.dims.size() == 2) {
+      EmP1Fn fn = em_p1_lookup(g.dims[0], g.dims[1]);
+      if (!fn) return 0;
+      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
+      return launch_ok() ? 1 : -1;
+    }
+    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
+      hipLaunchKernelGGL((em_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles,
+                         nchunks, partial);
+      return launch_ok() ? 1 : -1;
+    }
+    return 0;
+  }
+}
+
+}  // namespace bn

@@ -282,263 +282,6 @@ __global__ void __launch_bounds__(256) variable_small_fast(float* __restrict__ a
 }
 
 // ---------------------------------------------------------------------------------
-// Wide variable node (fan-in in the hundreds): three kernels.
-//   wide_product : each wave multiplies a chunk of the inputs -> partial product per state,
-//                  as double mantissa + int exponent            grid (chunks x tiles)
-//   wide_combine : multiplies the partials and the remaining inputs, writes c, the message
-//                  to the local factor, and P'[s] = P[s] / 2^emax as doubles  grid (tiles)
-//   wide_emit    : out_i[s] = (P'[s]/in_i[s]) / sum_s'(P'[s']/in_i[s'])  grid (chunks x tiles)
-// Chunked inputs are the first n_chunked = chunks * chunk_len input slots of the node (its
-// children); the rest (at most a few: tail children, observation, local factor) are folded in
-// by wide_combine.
-struct WideArgs {
-  const int64_t* in_off;   // [I] for this node
-  const int64_t* out_off;  // [I]
-  int64_t c_off;
-  int32_t I;
-  int32_t chunks, chunk_len;
-  double* part_mant;  // [chunks][S][npad]
-  int32_t* part_exp;  // [chunks][S][npad]
-  double* scaled;     // [S][npad]   P'[s]
-  int64_t npad;
-  int64_t ntiles;
-  int32_t fresh;
-};
-
-template <int S>
-__global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict__ arena, WideArgs a) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (w >= (int64_t)a.chunks * a.ntiles) return;
-  const int32_t chunk = (int32_t)(w / a.ntiles);
-  const int64_t t = w % a.ntiles;
-
-  double m[S][4];
-  int32_t e[S][4];
-#pragma unroll
-  for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
-      m[s][v] = 1.0;
-      e[s][v] = 0;
-    }
-  const int32_t first = chunk * a.chunk_len;
-  if (!a.fresh) {
-    for (int32_t j = 0; j < a.chunk_len; ++j) {
-      const float* src = arena + a.in_off[first + j];
-#pragma unroll
-      for (int32_t s = 0; s < S; ++s) {
-        const f4 x = load4(src, t * S + s, lane);
-#pragma unroll
-        for (int32_t v = 0; v < 4; ++v) m[s][v] *= (double)x.v[v];
-      }
-      if ((j & 3) == 3 || j == a.chunk_len - 1) {
-#pragma unroll
-        for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-          for (int32_t v = 0; v < 4; ++v) {
-            int de = 0;
-            m[s][v] = frexp(m[s][v], &de);
-            e[s][v] += de;
-          }
-      }
-    }
-  } else {
-    // all chunked inputs still hold 1/S
-    const double u = 1.0 / (double)S;
-    for (int32_t j = 0; j < a.chunk_len; ++j) {
-#pragma unroll
-      for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-        for (int32_t v = 0; v < 4; ++v) m[s][v] *= u;
-      if ((j & 3) == 3 || j == a.chunk_len - 1) {
-#pragma unroll
-        for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-          for (int32_t v = 0; v < 4; ++v) {
-            int de = 0;
-            m[s][v] = frexp(m[s][v], &de);
-            e[s][v] += de;
-          }
-      }
-    }
-  }
-#pragma unroll
-  for (int32_t s = 0; s < S; ++s) {
-    const int64_t row = ((int64_t)chunk * S + s) * a.npad + t * kTile + lane * 4;
-    *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(m[s][0], m[s][1]);
-    *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(m[s][2], m[s][3]);
-    *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(e[s][0], e[s][1], e[s][2], e[s][3]);
-  }
-}
-
-template <int S>
-__global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (t >= a.ntiles) return;
-
-  double m[S][4];
-  int32_t e[S][4];
-#pragma unroll
-  for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
-      m[s][v] = 1.0;
-      e[s][v] = 0;
-    }
-  for (int32_t ch = 0; ch < a.chunks; ++ch) {
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      const int64_t row = ((int64_t)ch * S + s) * a.npad + t * kTile + lane * 4;
-      const double2 lo = *reinterpret_cast<const double2*>(a.part_mant + row);
-      const double2 hi = *reinterpret_cast<const double2*>(a.part_mant + row + 2);
-      const int4 ex = *reinterpret_cast<const int4*>(a.part_exp + row);
-      m[s][0] *= lo.x;
-      m[s][1] *= lo.y;
-      m[s][2] *= hi.x;
-      m[s][3] *= hi.y;
-      e[s][0] += ex.x;
-      e[s][1] += ex.y;
-      e[s][2] += ex.z;
-      e[s][3] += ex.w;
-    }
-    if ((ch & 3) == 3) {
-#pragma unroll
-      for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-        for (int32_t v = 0; v < 4; ++v) {
-          int de = 0;
-          m[s][v] = frexp(m[s][v], &de);
-          e[s][v] += de;
-        }
-    }
-  }
-  // the inputs that were not chunked
-  const int32_t n_chunked = a.chunks * a.chunk_len;
-  f4 local[S];
-  const float uniform = 1.0f / (float)S;
-  for (int32_t i = n_chunked; i < a.I; ++i) {
-    const bool skip = a.fresh && a.out_off[i] >= 0;
-    const float* src = arena + a.in_off[i];
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      f4 x;
-      if (skip) {
-        x = f4{{uniform, uniform, uniform, uniform}};
-      } else {
-        x = load4(src, t * S + s, lane);
-      }
-      if (i == a.I - 1) local[s] = x;
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
-        int de = 0;
-        m[s][v] = frexp(m[s][v] * (double)x.v[v], &de);
-        e[s][v] += de;
-      }
-    }
-  }
-
-  int32_t emax[4];
-  double z[4];
-#pragma unroll
-  for (int32_t v = 0; v < 4; ++v) {
-    emax[v] = kDeadExponent;
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      int de = 0;
-      m[s][v] = frexp(m[s][v], &de);
-      e[s][v] = m[s][v] == 0.0 ? kDeadExponent : e[s][v] + de;
-      emax[v] = e[s][v] > emax[v] ? e[s][v] : emax[v];
-    }
-    z[v] = 0.0;
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      m[s][v] = ldexp(m[s][v], clamp_shift(e[s][v] - emax[v]));  // P'[s]
-      z[v] += m[s][v];
-    }
-  }
-  {
-    f4 c;
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) c.v[v] = (float)((double)emax[v] * 0.6931471805599453 + log(z[v]));
-    store4(arena + a.c_off, t, lane, c);
-  }
-  // message to the local factor: (P'/in_local) / z
-  {
-    float* dst = arena + a.out_off[a.I - 1];
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      f4 o;
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(m[s][v] / (double)local[s].v[v] / z[v]);
-      store4(dst, t * S + s, lane, o);
-    }
-  }
-#pragma unroll
-  for (int32_t s = 0; s < S; ++s) {
-    const int64_t row = (int64_t)s * a.npad + t * kTile + lane * 4;
-    *reinterpret_cast<double2*>(a.scaled + row) = make_double2(m[s][0], m[s][1]);
-    *reinterpret_cast<double2*>(a.scaled + row + 2) = make_double2(m[s][2], m[s][3]);
-  }
-}
-
-template <int S>
-__global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena, WideArgs a, int32_t emit_chunks,
-                                                     int32_t emit_len) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (w >= (int64_t)emit_chunks * a.ntiles) return;
-  const int32_t chunk = (int32_t)(w / a.ntiles);
-  const int64_t t = w % a.ntiles;
-
-  double p[S][4];
-#pragma unroll
-  for (int32_t s = 0; s < S; ++s) {
-    const int64_t row = (int64_t)s * a.npad + t * kTile + lane * 4;
-    const double2 lo = *reinterpret_cast<const double2*>(a.scaled + row);
-    const double2 hi = *reinterpret_cast<const double2*>(a.scaled + row + 2);
-    p[s][0] = lo.x;
-    p[s][1] = lo.y;
-    p[s][2] = hi.x;
-    p[s][3] = hi.y;
-  }
-  const int32_t first = chunk * emit_len;
-  const int32_t last = first + emit_len < a.I - 1 ? first + emit_len : a.I - 1;  // local slot excluded
-  const float uniform = 1.0f / (float)S;
-  for (int32_t i = first; i < last; ++i) {
-    const int64_t dst = a.out_off[i];
-    if (dst < 0) continue;
-    const float* src = arena + a.in_off[i];
-    double q[S][4];
-    double sum[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      f4 x;
-      if (a.fresh) {
-        x = f4{{uniform, uniform, uniform, uniform}};
-      } else {
-        x = load4(src, t * S + s, lane);
-      }
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
-        q[s][v] = p[s][v] / (double)x.v[v];
-        sum[v] += q[s][v];
-      }
-    }
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) sum[v] = 1.0 / sum[v];
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      f4 o;
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(q[s][v] * sum[v]);
-      store4(arena + dst, t * S + s, lane, o);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // EM expected counts, one parent (D0) + own variable (S), or no parent (D0 = 1, the
 // parent message is the constant 1): per lane running sums of in_parent[a] * in_own[b]
 // over the observations of the wave's tile range, then a wave reduction.  The CPT factor
@@ -759,202 +502,5 @@ inline VarSmallFn var_small_lookup(int32_t fan_in, int32_t s) {
 inline uint32_t wave_blocks(int64_t items) { return (uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock); }
 
 inline bool launch_ok() { return hipGetLastError() == hipSuccess; }
-
-// ---- wide variable nodes: scratch layout --------------------------------------------
-struct WidePlan {
-  int32_t chunks = 0, chunk_len = 0;      // product chunks over the first chunks*chunk_len inputs
-  int32_t emit_chunks = 0, emit_len = 0;  // emission chunks over inputs [0, I-1)
-  double* part_mant = nullptr;
-  int32_t* part_exp = nullptr;
-  double* scaled = nullptr;
-};
-
-inline bool is_wide(const Plan& p, const VariableGroup& g) {
-  return p.dtype == 0 && g.num_inputs > kWideFanIn && g.num_states <= kWideMaxStates;
-}
-
-inline void wide_geometry(const Plan& p, const VariableGroup& g, WidePlan& w) {
-  // aim for ~4096 waves per launch, chunks of at least 8 inputs
-  const int32_t I = g.num_inputs;
-  int64_t want = (4096 + p.ntiles - 1) / p.ntiles;
-  int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, I / 8));
-  w.chunk_len = (I - 2) / chunks;  // the last two slots (observation or last child, local factor) are never chunked
-  w.chunks = chunks;
-  w.emit_len = w.chunk_len;
-  w.emit_chunks = ((I - 1) + w.emit_len - 1) / w.emit_len;
-}
-
-}  // namespace bn
-
-// The per-plan wide scratch lives in a side table keyed by (plan, group index) so that plan.h
-// stays free of kernel-specific state.
-#include <map>
-
-namespace bn {
-
-struct FastState {
-  std::map<int32_t, WidePlan> wide;  // variable group index -> scratch
-};
-
-inline std::map<const Plan*, FastState>& fast_states() {
-  static std::map<const Plan*, FastState> states;
-  return states;
-}
-
-inline int64_t fast_scratch_elems(const Plan&) { return 0; }
-
-inline int prepare_fast(Plan& p) {
-  FastState st;
-  for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
-    const VariableGroup& g = p.vgroups[gi];
-    if (!is_wide(p, g)) continue;
-    WidePlan w;
-    wide_geometry(p, g, w);
-    const size_t S = g.num_states;
-    const size_t nodes = g.nodes.size();
-    // scratch is reused node after node within the group (launches are stream-ordered)
-    (void)nodes;
-    if (hipMalloc(reinterpret_cast<void**>(&w.part_mant), (size_t)w.chunks * S * p.npad * sizeof(double)) != hipSuccess)
-      return -2;
-    if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), (size_t)w.chunks * S * p.npad * sizeof(int32_t)) != hipSuccess)
-      return -2;
-    if (hipMalloc(reinterpret_cast<void**>(&w.scaled), S * p.npad * sizeof(double)) != hipSuccess) return -2;
-    p.device_bytes += (int64_t)((size_t)w.chunks * S * p.npad * 12 + S * p.npad * 8);
-    st.wide[(int32_t)gi] = w;
-  }
-  fast_states()[&p] = st;
-  return 0;
-}
-
-inline void release_fast(Plan& p) {
-  auto it = fast_states().find(&p);
-  if (it == fast_states().end()) return;
-  for (auto& kv : it->second.wide) {
-    if (kv.second.part_mant) (void)hipFree(kv.second.part_mant);
-    if (kv.second.part_exp) (void)hipFree(kv.second.part_exp);
-    if (kv.second.scaled) (void)hipFree(kv.second.scaled);
-  }
-  fast_states().erase(it);
-}
-
-template <int S>
-inline bool launch_wide_node(const Plan& p, const VariableGroup& g, const WidePlan& w, size_t k, float* arena,
-                             int32_t fresh, hipStream_t s) {
-  WideArgs a;
-  a.in_off = g.d_in + k * g.num_inputs;
-  a.out_off = g.d_out + k * g.num_inputs;
-  a.c_off = g.c_off[k];
-  a.I = g.num_inputs;
-  a.chunks = w.chunks;
-  a.chunk_len = w.chunk_len;
-  a.part_mant = w.part_mant;
-  a.part_exp = w.part_exp;
-  a.scaled = w.scaled;
-  a.npad = p.npad;
-  a.ntiles = p.ntiles;
-  a.fresh = fresh;
-  hipLaunchKernelGGL(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
-  if (!launch_ok()) return false;
-  hipLaunchKernelGGL(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles)), dim3(256), 0, s, arena, a);
-  if (!launch_ok()) return false;
-  hipLaunchKernelGGL(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.emit_chunks * p.ntiles)), dim3(256), 0, s, arena, a,
-                     w.emit_chunks, w.emit_len);
-  return launch_ok();
-}
-
-template <typename T>
-int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, hipStream_t s) {
-  if constexpr (!std::is_same<T, float>::value) {
-    return 0;
-  } else {
-    float* arena = arena_t;
-    const int32_t K = (int32_t)g.nodes.size();
-    if (is_wide(p, g)) {
-      auto it = fast_states().find(&p);
-      if (it == fast_states().end()) return 0;
-      auto wit = it->second.wide.find((int32_t)(&g - p.vgroups.data()));
-      if (wit == it->second.wide.end()) return 0;
-      for (size_t k = 0; k < g.nodes.size(); ++k) {
-        bool ok = false;
-        switch (g.num_states) {
-#define X(SV)                                                    \
-  case SV:                                                       \
-    ok = launch_wide_node<SV>(p, g, wit->second, k, arena, fresh, s); \
-    break;
-          BN_SMALL_DIMS(X)
-#undef X
-          default:
-            return k == 0 ? 0 : -1;
-        }
-        if (!ok) return -1;
-      }
-      return 1;
-    }
-    if (g.num_inputs * g.num_states > 12) return 0;  // per-lane state would not fit the register budget
-    VarSmallFn fn = var_small_lookup(g.num_inputs, g.num_states);
-    if (!fn) return 0;
-    hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K,
-                       p.ntiles, fresh);
-    return launch_ok() ? 1 : -1;
-  }
-}
-
-template <typename T>
-int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, hipStream_t s) {
-  if constexpr (!std::is_same<T, float>::value) {
-    return 0;
-  } else {
-    float* arena = arena_t;
-    const float* cpts = cpts_t;
-    const int32_t K = (int32_t)g.nodes.size();
-    const uint32_t blocks = wave_blocks((int64_t)K * p.ntiles);
-    if (g.dims.size() == 1) {
-      hipLaunchKernelGGL(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
-                         p.ntiles);
-      return launch_ok() ? 1 : -1;
-    }
-    if (g.dims.size() == 2) {
-      FactorP1Fn fn = factor_p1_lookup(g.dims[0], g.dims[1]);
-      if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
-      return launch_ok() ? 1 : -1;
-    }
-    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      hipLaunchKernelGGL((factor_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt,
-                         K, p.ntiles);
-      return launch_ok() ? 1 : -1;
-    }
-    return 0;
-  }
-}
-
-template <typename T>
-int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, double* partial, hipStream_t s) {
-  if constexpr (!std::is_same<T, float>::value) {
-    return 0;
-  } else {
-    const float* arena = arena_t;
-    const int32_t K = (int32_t)g.nodes.size();
-    const uint32_t blocks = wave_blocks((int64_t)K * nchunks);
-    if (g.dims.size() == 1) {
-      EmP1Fn fn = em_root_lookup(g.dims[0]);
-      if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
-      return launch_ok() ? 1 : -1;
-    }
-    if (g.dims.size() == 2) {
-      EmP1Fn fn = em_p1_lookup(g.dims[0], g.dims[1]);
-      if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
-      return launch_ok() ? 1 : -1;
-    }
-    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      hipLaunchKernelGGL((em_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles,
-                         nchunks, partial);
-      return launch_ok() ? 1 : -1;
-    }
-    return 0;
-  }
-}
 
 }  // namespace bn

@@ -1,0 +1,532 @@
+// Wide variable nodes (fan-in in the hundreds) and the leaf-family kernel fused around them.
+//
+// A wide node's product P[s] = prod_i in_i[s] cannot be formed by one wave without reading
+// megabytes per tile, so it is built from PARTIAL products over chunks of inputs, each a
+// double mantissa + int exponent per (state, observation):
+//
+//   wide_product   one wave per (chunk, tile) multiplies the chunk's inputs         (standalone)
+//   wide_combine   one wave per tile multiplies the partials and the few inputs that no
+//                  partial covers, writes c = log sum P, the scaled product
+//                  P'[s] = P[s] / 2^emax (doubles), and the outgoing messages of the
+//                  uncovered inputs (always including the message to the local factor)
+//   wide_emit      one wave per (chunk, tile): out_i[s] = (P'[s]/in_i[s]) / sum_s' (...)  (standalone)
+//
+// When the wide node's children are LEAF FAMILIES — factor nodes with that single parent
+// whose own variable has no children — one kernel does the whole iteration for them:
+//
+//   leaf_family_p1 one wave per (chunk of families, tile); per family k it
+//                    reads  the factor's previous messages f2v_{k->parent}, f2v_{k->own} and the
+//                           own variable's observation,
+//                    forms  the parent's message to the factor from P' (the wide emission) and
+//                           the own variable's message to the factor and normaliser c (its
+//                           whole variable pass: inputs are just observation x previous message),
+//                    runs   both contractions with the CPT,
+//                    writes the new f2v messages over the old ones, and
+//                    folds  the new message to the parent into the chunk's partial product for
+//                           the next iteration's wide_combine.
+//   The variable -> factor messages never touch HBM inside the loop; they are stored only in
+//   the last iteration of a bn_iterate call, for marginal / EM queries.
+//   Per observation and iteration this moves D0+2S floats in and D0+S+1 out per family (27
+//   floats for the 784-leaf model's (10,2) families) instead of the 61 of the unfused passes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fast.h"
+
+namespace bn {
+
+struct WideArgs {
+  const int64_t* in_off;   // [I]  this node's input offsets (f2v arrays / observation)
+  const int64_t* out_off;  // [I]  matching output offsets (v2f arrays), -1 = dead
+  int64_t c_off;
+  int32_t I;
+  // partial products
+  int32_t chunks, chunk_len, n_covered;
+  const int32_t* covered;    // [n_covered] input slots represented in the partials, chunk order
+  const int32_t* uncovered;  // [n_uncovered] input slots folded by wide_combine; last = local slot
+  int32_t n_uncovered;
+  double* part_mant;  // [chunks][S][npad]
+  int32_t* part_exp;  // [chunks][S][npad]
+  double* scaled;     // [S][npad]   P'[s]
+  int64_t npad;
+  int64_t ntiles;
+  int32_t fresh;
+};
+
+template <int S>
+__device__ __forceinline__ void renorm(double (&m)[S][4], int32_t (&e)[S][4]) {
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      int de = 0;
+      m[s][v] = frexp(m[s][v], &de);
+      e[s][v] += de;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void store_partial(const WideArgs& a, int32_t chunk, int64_t t, int32_t lane,
+                                              const double (&m)[S][4], const int32_t (&e)[S][4]) {
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s) {
+    const int64_t row = ((int64_t)chunk * S + s) * a.npad + t * kTile + lane * 4;
+    *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(m[s][0], m[s][1]);
+    *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(m[s][2], m[s][3]);
+    *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(e[s][0], e[s][1], e[s][2], e[s][3]);
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict__ arena, WideArgs a) {
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles) return;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+
+  double m[S][4];
+  int32_t e[S][4];
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      m[s][v] = 1.0;
+      e[s][v] = 0;
+    }
+  const int32_t first = chunk * a.chunk_len;
+  const int32_t last = first + a.chunk_len < a.n_covered ? first + a.chunk_len : a.n_covered;
+  const double u = 1.0 / (double)S;
+  for (int32_t j = first; j < last; ++j) {
+    if (a.fresh) {
+      // covered inputs are factor messages, all still 1/S
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+        for (int32_t v = 0; v < 4; ++v) m[s][v] *= u;
+    } else {
+      const float* src = arena + a.in_off[a.covered[j]];
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) {
+        const f4 x = load4(src, t * S + s, lane);
+#pragma unroll
+        for (int32_t v = 0; v < 4; ++v) m[s][v] *= (double)x.v[v];
+      }
+    }
+    if (((j - first) & 3) == 3) renorm<S>(m, e);
+  }
+  renorm<S>(m, e);
+  store_partial<S>(a, chunk, t, lane, m, e);
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (t >= a.ntiles) return;
+
+  double m[S][4];
+  int32_t e[S][4];
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      m[s][v] = 1.0;
+      e[s][v] = 0;
+    }
+  for (int32_t ch = 0; ch < a.chunks; ++ch) {
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      const int64_t row = ((int64_t)ch * S + s) * a.npad + t * kTile + lane * 4;
+      const double2 lo = *reinterpret_cast<const double2*>(a.part_mant + row);
+      const double2 hi = *reinterpret_cast<const double2*>(a.part_mant + row + 2);
+      const int4 ex = *reinterpret_cast<const int4*>(a.part_exp + row);
+      m[s][0] *= lo.x;
+      m[s][1] *= lo.y;
+      m[s][2] *= hi.x;
+      m[s][3] *= hi.y;
+      e[s][0] += ex.x;
+      e[s][1] += ex.y;
+      e[s][2] += ex.z;
+      e[s][3] += ex.w;
+    }
+    if ((ch & 3) == 3) renorm<S>(m, e);
+  }
+  // inputs no partial covers
+  const float uniform = 1.0f / (float)S;
+  for (int32_t u = 0; u < a.n_uncovered; ++u) {
+    const int32_t i = a.uncovered[u];
+    const bool skip = a.fresh && a.out_off[i] >= 0;
+    const float* src = arena + a.in_off[i];
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      f4 x;
+      if (skip) {
+        x = f4{{uniform, uniform, uniform, uniform}};
+      } else {
+        x = load4(src, t * S + s, lane);
+      }
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) m[s][v] *= (double)x.v[v];
+    }
+    renorm<S>(m, e);
+  }
+
+  double z[4];
+#pragma unroll
+  for (int32_t v = 0; v < 4; ++v) {
+    int32_t emax = kDeadExponent;
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      int de = 0;
+      m[s][v] = frexp(m[s][v], &de);
+      e[s][v] = m[s][v] == 0.0 ? kDeadExponent : e[s][v] + de;
+      emax = e[s][v] > emax ? e[s][v] : emax;
+    }
+    z[v] = 0.0;
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      m[s][v] = ldexp(m[s][v], clamp_shift(e[s][v] - emax));  // P'[s]
+      z[v] += m[s][v];
+    }
+    e[0][v] = emax;
+  }
+  {
+    f4 c;
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) c.v[v] = (float)((double)e[0][v] * 0.6931471805599453 + log(z[v]));
+    store4(arena + a.c_off, t, lane, c);
+  }
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s) {
+    const int64_t row = (int64_t)s * a.npad + t * kTile + lane * 4;
+    *reinterpret_cast<double2*>(a.scaled + row) = make_double2(m[s][0], m[s][1]);
+    *reinterpret_cast<double2*>(a.scaled + row + 2) = make_double2(m[s][2], m[s][3]);
+  }
+  // outgoing messages of the uncovered inputs
+  for (int32_t u = 0; u < a.n_uncovered; ++u) {
+    const int32_t i = a.uncovered[u];
+    const int64_t dst = a.out_off[i];
+    if (dst < 0) continue;
+    const bool skip = a.fresh != 0;
+    const float* src = arena + a.in_off[i];
+    double q[S][4];
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      f4 x;
+      if (skip) {
+        x = f4{{uniform, uniform, uniform, uniform}};
+      } else {
+        x = load4(src, t * S + s, lane);
+      }
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) {
+        q[s][v] = m[s][v] / (double)x.v[v];
+        sum[v] += q[s][v];
+      }
+    }
+    const bool local = (i == a.I - 1);
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) sum[v] = 1.0 / (local ? z[v] : sum[v]);
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      f4 o;
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(q[s][v] * sum[v]);
+      store4(arena + dst, t * S + s, lane, o);
+    }
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena, WideArgs a) {
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles) return;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+
+  double p[S][4];
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s) {
+    const int64_t row = (int64_t)s * a.npad + t * kTile + lane * 4;
+    const double2 lo = *reinterpret_cast<const double2*>(a.scaled + row);
+    const double2 hi = *reinterpret_cast<const double2*>(a.scaled + row + 2);
+    p[s][0] = lo.x;
+    p[s][1] = lo.y;
+    p[s][2] = hi.x;
+    p[s][3] = hi.y;
+  }
+  const int32_t first = chunk * a.chunk_len;
+  const int32_t last = first + a.chunk_len < a.n_covered ? first + a.chunk_len : a.n_covered;
+  const float uniform = 1.0f / (float)S;
+  for (int32_t j = first; j < last; ++j) {
+    const int32_t i = a.covered[j];
+    const int64_t dst = a.out_off[i];
+    if (dst < 0) continue;
+    const float* src = arena + a.in_off[i];
+    double q[S][4];
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      f4 x;
+      if (a.fresh) {
+        x = f4{{uniform, uniform, uniform, uniform}};
+      } else {
+        x = load4(src, t * S + s, lane);
+      }
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) {
+        q[s][v] = p[s][v] / (double)x.v[v];
+        sum[v] += q[s][v];
+      }
+    }
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) sum[v] = 1.0 / sum[v];
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      f4 o;
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(q[s][v] * sum[v]);
+      store4(arena + dst, t * S + s, lane, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Leaf families with one (wide) parent: see the file header.
+struct LeafFamilyArgs {
+  const int64_t* f_in;     // [K*2]  v2f offsets of the factor group (parent slot, own slot)
+  const int64_t* f_out;    // [K*2]  f2v offsets
+  const int64_t* cpt_off;  // [K]
+  const int64_t* obs_off;  // [K]    observation array of the own variable, -1 = not observed
+  const int64_t* c_off;    // [K]    normaliser of the own variable
+  int32_t K;
+  int32_t chunks, chunk_len;
+  double* part_mant;
+  int32_t* part_exp;
+  const double* scaled;  // parent's P'
+  int64_t npad;
+  int64_t ntiles;
+  int32_t fresh;
+  int32_t store_v2f;
+};
+
+// 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
+// seed plus one Newton step.
+__device__ __forceinline__ double recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+
+template <int V>
+struct fv {
+  float v[V];
+};
+
+template <int V>
+__device__ __forceinline__ fv<V> loadv(const float* __restrict__ base, int64_t row, int32_t col) {
+  fv<V> r;
+  if constexpr (V == 4) {
+    const float4 x = *reinterpret_cast<const float4*>(base + row * kTile + col);
+    r.v[0] = x.x;
+    r.v[1] = x.y;
+    r.v[2] = x.z;
+    r.v[3] = x.w;
+  } else {
+    const float2 x = *reinterpret_cast<const float2*>(base + row * kTile + col);
+    r.v[0] = x.x;
+    r.v[1] = x.y;
+  }
+  return r;
+}
+
+template <int V>
+__device__ __forceinline__ void storev(float* __restrict__ base, int64_t row, int32_t col, const fv<V>& r) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(base + row * kTile + col) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else {
+    *reinterpret_cast<float2*>(base + row * kTile + col) = make_float2(r.v[0], r.v[1]);
+  }
+}
+
+template <int V>
+__device__ __forceinline__ fv<V> splat(float x) {
+  fv<V> r;
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) r.v[v] = x;
+  return r;
+}
+
+// V observations per lane: a wave covers 64*V observations, i.e. 4/V work items per tile.
+template <int D0, int S, int V>
+__global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
+                                                     LeafFamilyArgs a) {
+  constexpr int32_t kParts = 4 / V;
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
+  const int32_t part = (int32_t)(w % kParts);
+  w /= kParts;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+  const int32_t col = part * 64 * V + lane * V;  // first observation of this lane inside the tile
+
+  double pm[D0][V];
+  int32_t pe[D0][V];
+#pragma unroll
+  for (int32_t s = 0; s < D0; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      pm[s][v] = 1.0;
+      pe[s][v] = 0;
+    }
+
+  const int32_t first = chunk * a.chunk_len;
+  const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
+  const float u_par = 1.0f / (float)D0, u_own = 1.0f / (float)S;
+  const double* scaled = a.scaled + t * kTile + col;
+  for (int32_t k = first; k < last; ++k) {
+    float* f2v_par = arena + a.f_out[2 * k];
+    float* f2v_own = arena + a.f_out[2 * k + 1];
+    const int64_t obs = a.obs_off[k];
+    const float* cpt = cpts + a.cpt_off[k];
+
+    fv<V> prev_par[D0], prev_own[S], ev[S];
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) prev_par[i] = a.fresh ? splat<V>(u_par) : loadv<V>(f2v_par, t * D0 + i, col);
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) {
+      prev_own[j] = a.fresh ? splat<V>(u_own) : loadv<V>(f2v_own, t * S + j, col);
+      ev[j] = obs >= 0 ? loadv<V>(arena + obs, t * S + j, col) : splat<V>(1.f);
+    }
+
+    // own (leaf) variable: P = ev * prev_own, c = log sum P, message to the factor = ev / sum P
+    fv<V> to_f_own[S];
+    {
+      double z[V];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) z[v] = 0.0;
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) z[v] = fma((double)ev[j].v[v], (double)prev_own[j].v[v], z[v]);
+      fv<V> c;
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        int de = 0;
+        const double mz = frexp(z[v], &de);
+        c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
+        z[v] = recip(z[v]);
+      }
+      storev<V>(arena + a.c_off[k], t, col, c);
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = (float)((double)ev[j].v[v] * z[v]);
+    }
+    // wide parent: message to this factor = (P'/prev_par) normalised.  P' is re-read per family
+    // (it is shared by every wave working on this tile, so it comes from L2).
+    fv<V> to_f_par[D0];
+    {
+      double q[D0][V];
+      double sum[V];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) sum[v] = 0.0;
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        double pv[V];
+        if constexpr (V == 4) {
+          const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
+          const double2 hi = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad + 2);
+          pv[0] = lo.x;
+          pv[1] = lo.y;
+          pv[2] = hi.x;
+          pv[3] = hi.y;
+        } else {
+          const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
+          pv[0] = lo.x;
+          pv[1] = lo.y;
+        }
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          q[i][v] = pv[v] * recip((double)prev_par[i].v[v]);
+          sum[v] += q[i][v];
+        }
+      }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) sum[v] = recip(sum[v]);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] = (float)(q[i][v] * sum[v]);
+    }
+    if (a.store_v2f) {
+      float* v2f_par = arena + a.f_in[2 * k];
+      float* v2f_own = arena + a.f_in[2 * k + 1];
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) storev<V>(v2f_par, t * D0 + i, col, to_f_par[i]);
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) storev<V>(v2f_own, t * S + j, col, to_f_own[j]);
+    }
+    // factor contractions
+    fv<V> new_par[D0], new_own[S];
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) new_par[i] = splat<V>(0.f);
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) new_own[j] = splat<V>(0.f);
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) {
+        const float cv = cpt[i * S + j];
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          new_par[i].v[v] = fmaf(cv, to_f_own[j].v[v], new_par[i].v[v]);
+          new_own[j].v[v] = fmaf(cv, to_f_par[i].v[v], new_own[j].v[v]);
+        }
+      }
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) storev<V>(f2v_par, t * D0 + i, col, new_par[i]);
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) storev<V>(f2v_own, t * S + j, col, new_own[j]);
+    // fold into the partial product for the parent's next combine
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) pm[i][v] *= (double)new_par[i].v[v];
+    if (((k - first) & 3) == 3) {
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          pm[i][v] = frexp(pm[i][v], &de);
+          pe[i][v] += de;
+        }
+    }
+  }
+#pragma unroll
+  for (int32_t s = 0; s < D0; ++s) {
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      pm[s][v] = frexp(pm[s][v], &de);
+      pe[s][v] += de;
+    }
+    const int64_t row = ((int64_t)chunk * D0 + s) * a.npad + t * kTile + col;
+    if constexpr (V == 4) {
+      *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
+      *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(pm[s][2], pm[s][3]);
+      *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(pe[s][0], pe[s][1], pe[s][2], pe[s][3]);
+    } else {
+      *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
+      *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(pe[s][0], pe[s][1]);
+    }
+  }
+}
+
+}  // namespace bn

@@ -108,6 +108,8 @@ struct Plan {
   // true while every message still has its initial uniform value and the arrays have not
   // been written: the first variable pass then uses 1/S directly instead of reading them
   bool fresh = false;
+  // observation slots still owe their uniform reset value (skipped when evidence arrives first)
+  bool obs_pending = false;
 
 };
 
