@@ -81,18 +81,29 @@ std::mutex g_prof_mutex;
 std::vector<ProfRecord> g_prof;
 std::atomic<bool> g_profiling{false};
 
+std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than recording it
+
+bool take_event(hipEvent_t* ev) {
+  if (!g_event_pool.empty()) {
+    *ev = g_event_pool.back();
+    g_event_pool.pop_back();
+    return true;
+  }
+  return hipEventCreate(ev) == hipSuccess;
+}
+
 void prof_begin(const std::string& label, double alg_bytes, hipStream_t s) {
   if (!g_profiling.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   ProfRecord r;
   r.label = label;
   r.alg_bytes = alg_bytes;
-  if (hipEventCreate(&r.start) != hipSuccess) return;
-  if (hipEventCreate(&r.stop) != hipSuccess) {
-    (void)hipEventDestroy(r.start);
+  if (!take_event(&r.start)) return;
+  if (!take_event(&r.stop)) {
+    g_event_pool.push_back(r.start);
     return;
   }
   (void)hipEventRecord(r.start, s);
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
   g_prof.push_back(std::move(r));
 }
 
@@ -247,7 +258,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
         bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
         prof_begin(label, bytes, s);
       }
-      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == iterations - 1 ? 1 : 0, s);
+      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
       if (rc == 0) {
         bn::FactorDims fd = make_dims(g.dims);
@@ -642,8 +653,9 @@ int bn_profile_report(char* buffer, int64_t capacity) {
       total_ms[i] += ms;
       launches[i] += 1;
     }
-    (void)hipEventDestroy(r.start);
-    (void)hipEventDestroy(r.stop);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_event_pool.push_back(r.start);
+    g_event_pool.push_back(r.stop);
   }
   std::string json = "[";
   for (size_t i = 0; i < labels.size(); ++i) {

@@ -5,6 +5,8 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -18,7 +20,6 @@
 namespace bn {
 
 constexpr int32_t kMaxUncovered = 8;
-constexpr int32_t kLeafVec = 2;  // observations per lane in the leaf-family kernel (register budget)
 
 struct WideNode {
   int32_t node = -1, vgroup = -1, vpos = -1;
@@ -208,6 +209,13 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   a.npad = p.npad;
   a.ntiles = p.ntiles;
   a.fresh = fresh;
+  {
+    // (1/S)^n as mantissa * 2^exponent
+    const double log2p = -(double)w.covered.size() * std::log2((double)w.S);
+    const double fl = std::floor(log2p);
+    a.fresh_mant = std::exp2(log2p - fl);
+    a.fresh_exp = (int32_t)fl;
+  }
   return a;
 }
 
@@ -216,7 +224,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
                              hipStream_t s) {
   const WideArgs a = wide_args(p, g, w, fresh);
   const bool fused = w.fused_fgroup >= 0;
-  if (!fused || !w.partials_valid) {
+  if (!fresh && (!fused || !w.partials_valid)) {
     hipLaunchKernelGGL(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
     if (!launch_ok()) return false;
   }
@@ -315,32 +323,41 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
 
 using LeafFamilyFn = void (*)(float*, const float*, LeafFamilyArgs);
 
-template <int D0>
+template <int D0, int V>
 inline LeafFamilyFn leaf_family_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return leaf_family_p1<D0, SV, kLeafVec>;
+    return leaf_family_p1<D0, SV, V>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
+template <int V>
 inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return leaf_family_for_s<DV>(s);
+    return leaf_family_for_s<DV, V>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
+// observations per lane in the leaf-family kernel (2 measured fastest for both modes on the
+// 784-leaf model: 4 leaves one wave per SIMD, 1 doubles the per-family instruction overhead)
+inline int32_t leaf_vec(bool store_full) {
+  static const int32_t loop_vec = getenv("BN_LEAF_VEC_LOOP") ? atoi(getenv("BN_LEAF_VEC_LOOP")) : 2;
+  static const int32_t full_vec = getenv("BN_LEAF_VEC_FULL") ? atoi(getenv("BN_LEAF_VEC_FULL")) : 2;
+  return store_full ? full_vec : loop_vec;
+}
+
 template <typename T>
-int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t last_iteration,
-                       hipStream_t s) {
+int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t first_iteration,
+                       int32_t last_iteration, hipStream_t s) {
   if constexpr (!std::is_same<T, float>::value) {
     return 0;
   } else {
@@ -354,7 +371,10 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       auto it = st->fused.find((int32_t)fi);
       if (it != st->fused.end()) {
         WideNode& w = st->wide[it->second.wide_index];
-        LeafFamilyFn fn = leaf_family_lookup(g.dims[0], g.dims[1]);
+        const int32_t vec = leaf_vec(last_iteration != 0);
+        LeafFamilyFn fn = vec == 1   ? leaf_family_lookup<1>(g.dims[0], g.dims[1])
+                          : vec == 4 ? leaf_family_lookup<4>(g.dims[0], g.dims[1])
+                                     : leaf_family_lookup<2>(g.dims[0], g.dims[1]);
         if (!fn) return -1;
         LeafFamilyArgs a;
         a.f_in = g.d_in;
@@ -371,9 +391,9 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
         a.npad = p.npad;
         a.ntiles = p.ntiles;
         a.fresh = fresh;
-        a.store_v2f = last_iteration;
-        hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts,
-                           a);
+        a.prev_from_arrays = first_iteration;
+        a.store_full = last_iteration;
+        hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / vec))), dim3(256), 0, s, arena, cpts, a);
         if (!launch_ok()) return -1;
         w.partials_valid = true;
         return 1;

@@ -52,6 +52,10 @@ struct WideArgs {
   int64_t npad;
   int64_t ntiles;
   int32_t fresh;
+  // while fresh, the covered inputs are all 1/S: their product (1/S)^n_covered is passed in
+  // as mantissa * 2^exponent and no partial is read
+  double fresh_mant;
+  int32_t fresh_exp;
 };
 
 template <int S>
@@ -135,7 +139,16 @@ __global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ are
       m[s][v] = 1.0;
       e[s][v] = 0;
     }
-  for (int32_t ch = 0; ch < a.chunks; ++ch) {
+  if (a.fresh) {
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+      for (int32_t v = 0; v < 4; ++v) {
+        m[s][v] = a.fresh_mant;
+        e[s][v] = a.fresh_exp;
+      }
+  }
+  for (int32_t ch = 0; ch < (a.fresh ? 0 : a.chunks); ++ch) {
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
       const int64_t row = ((int64_t)ch * S + s) * a.npad + t * kTile + lane * 4;
@@ -311,7 +324,12 @@ struct LeafFamilyArgs {
   int64_t npad;
   int64_t ntiles;
   int32_t fresh;
-  int32_t store_v2f;
+  // first iteration of a bn_iterate call: the factor's previous message to the parent is read
+  // from its array; later iterations rebuild it from the leaf's previous normaliser (see kernel)
+  int32_t prev_from_arrays;
+  // last iteration of a bn_iterate call: write everything queries may read (both variable ->
+  // factor messages, the message to the parent, c = log z); otherwise only the loop state
+  int32_t store_full;
 };
 
 // 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
@@ -336,10 +354,12 @@ __device__ __forceinline__ fv<V> loadv(const float* __restrict__ base, int64_t r
     r.v[1] = x.y;
     r.v[2] = x.z;
     r.v[3] = x.w;
-  } else {
+  } else if constexpr (V == 2) {
     const float2 x = *reinterpret_cast<const float2*>(base + row * kTile + col);
     r.v[0] = x.x;
     r.v[1] = x.y;
+  } else {
+    r.v[0] = base[row * kTile + col];
   }
   return r;
 }
@@ -348,8 +368,10 @@ template <int V>
 __device__ __forceinline__ void storev(float* __restrict__ base, int64_t row, int32_t col, const fv<V>& r) {
   if constexpr (V == 4) {
     *reinterpret_cast<float4*>(base + row * kTile + col) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
-  } else {
+  } else if constexpr (V == 2) {
     *reinterpret_cast<float2*>(base + row * kTile + col) = make_float2(r.v[0], r.v[1]);
+  } else {
+    base[row * kTile + col] = r.v[0];
   }
 }
 
@@ -362,6 +384,54 @@ __device__ __forceinline__ fv<V> splat(float x) {
 }
 
 // V observations per lane: a wave covers 64*V observations, i.e. 4/V work items per tile.
+//
+// The loop over the chunk's families is software-pipelined by hand: the small loop state of
+// family k+1 (its pointers, previous own message, observation, previous normaliser) is
+// requested before the arithmetic of family k, so that with two waves per SIMD the memory
+// latency of one family hides behind the arithmetic of the previous one.
+struct LeafPtrs {  // wave-uniform
+  float* f2v_par;
+  float* f2v_own;
+  float* v2f_par;
+  float* v2f_own;
+  float* c;
+  const float* obs;  // nullptr = not observed
+  const float* cpt;
+};
+
+template <int S, int V>
+struct LeafState {
+  fv<V> prev_own[S], ev[S];
+  fv<V> zp;  // previous normaliser
+};
+
+__device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const float* __restrict__ cpts,
+                                              const LeafFamilyArgs& a, int32_t k) {
+  LeafPtrs p;
+  p.f2v_par = arena + a.f_out[2 * k];
+  p.f2v_own = arena + a.f_out[2 * k + 1];
+  p.v2f_par = arena + a.f_in[2 * k];
+  p.v2f_own = arena + a.f_in[2 * k + 1];
+  p.c = arena + a.c_off[k];
+  const int64_t obs = a.obs_off[k];
+  p.obs = obs >= 0 ? arena + obs : nullptr;
+  p.cpt = cpts + a.cpt_off[k];
+  return p;
+}
+
+template <int S, int V>
+__device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const LeafFamilyArgs& a, int64_t t,
+                                                      int32_t col) {
+  LeafState<S, V> st;
+#pragma unroll
+  for (int32_t j = 0; j < S; ++j) {
+    st.prev_own[j] = a.fresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
+    st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
+  }
+  st.zp = (!a.fresh && !a.prev_from_arrays) ? loadv<V>(p.c, t, col) : splat<V>(1.f);
+  return st;
+}
+
 template <int D0, int S, int V>
 __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      LeafFamilyArgs a) {
@@ -387,24 +457,48 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 
   const int32_t first = chunk * a.chunk_len;
   const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
-  const float u_par = 1.0f / (float)D0, u_own = 1.0f / (float)S;
+  if (first >= last) return;
   const double* scaled = a.scaled + t * kTile + col;
-  for (int32_t k = first; k < last; ++k) {
-    float* f2v_par = arena + a.f_out[2 * k];
-    float* f2v_own = arena + a.f_out[2 * k + 1];
-    const int64_t obs = a.obs_off[k];
-    const float* cpt = cpts + a.cpt_off[k];
 
-    fv<V> prev_par[D0], prev_own[S], ev[S];
+  LeafPtrs ptr = leaf_ptrs(arena, cpts, a, first);
+  LeafState<S, V> cur = leaf_state<S, V>(ptr, a, t, col);
+  for (int32_t k = first; k < last; ++k) {
+    const int32_t kn = k + 1 < last ? k + 1 : k;
+    const LeafPtrs ptr_next = leaf_ptrs(arena, cpts, a, kn);
+    const LeafState<S, V> nxt = leaf_state<S, V>(ptr_next, a, t, col);
+    const float* cpt = ptr.cpt;
+
+    // Loop state per family between iterations: the factor's message to its own variable
+    // (f2v_own) and the leaf's normaliser z = sum_s ev[s] * f2v_own[s], kept in the c array.
+    // The factor's previous message to the parent is cpt . (ev / z_prev): recomputed from
+    // those 2+1 floats instead of stored and reloaded as D0 floats.
+    fv<V> prev_par[D0];
+    if (a.fresh) {
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) prev_par[i] = a.fresh ? splat<V>(u_par) : loadv<V>(f2v_par, t * D0 + i, col);
+      for (int32_t i = 0; i < D0; ++i) prev_par[i] = splat<V>(1.0f / (float)D0);
+    } else if (a.prev_from_arrays) {
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) {
-      prev_own[j] = a.fresh ? splat<V>(u_own) : loadv<V>(f2v_own, t * S + j, col);
-      ev[j] = obs >= 0 ? loadv<V>(arena + obs, t * S + j, col) : splat<V>(1.f);
+      for (int32_t i = 0; i < D0; ++i) prev_par[i] = loadv<V>(ptr.f2v_par, t * D0 + i, col);
+    } else {
+      fv<V> tfo[S];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        const double inv = recip((double)cur.zp.v[v]);
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) tfo[j].v[v] = (float)((double)cur.ev[j].v[v] * inv);
+      }
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        prev_par[i] = splat<V>(0.f);
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) prev_par[i].v[v] = fmaf(cpt[i * S + j], tfo[j].v[v], prev_par[i].v[v]);
+      }
     }
 
-    // own (leaf) variable: P = ev * prev_own, c = log sum P, message to the factor = ev / sum P
+    // own (leaf) variable: P = ev * prev_own, z = sum P, c = log z, message to the factor = ev / z
+    // (with z rounded to float first, so that the next iteration can rebuild the same message)
     fv<V> to_f_own[S];
     {
       double z[V];
@@ -413,23 +507,29 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
       for (int32_t j = 0; j < S; ++j)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) z[v] = fma((double)ev[j].v[v], (double)prev_own[j].v[v], z[v]);
+        for (int32_t v = 0; v < V; ++v) z[v] = fma((double)cur.ev[j].v[v], (double)cur.prev_own[j].v[v], z[v]);
       fv<V> c;
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
-        int de = 0;
-        const double mz = frexp(z[v], &de);
-        c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
-        z[v] = recip(z[v]);
+        const float zf = (float)z[v];
+        if (a.store_full) {
+          int de = 0;
+          const double mz = frexp(z[v], &de);
+          c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
+        } else {
+          c.v[v] = zf;
+        }
+        z[v] = recip((double)zf);
       }
-      storev<V>(arena + a.c_off[k], t, col, c);
+      storev<V>(ptr.c, t, col, c);
 #pragma unroll
       for (int32_t j = 0; j < S; ++j)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = (float)((double)ev[j].v[v] * z[v]);
+        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = (float)((double)cur.ev[j].v[v] * z[v]);
     }
     // wide parent: message to this factor = (P'/prev_par) normalised.  P' is re-read per family
-    // (it is shared by every wave working on this tile, so it comes from L2).
+    // (shared by every wave working on this tile, so it comes from L2).  The reciprocal is a
+    // float one: this message only reaches the leaf, its rounding does not enter the wide product.
     fv<V> to_f_par[D0];
     {
       double q[D0][V];
@@ -446,14 +546,16 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
           pv[1] = lo.y;
           pv[2] = hi.x;
           pv[3] = hi.y;
-        } else {
+        } else if constexpr (V == 2) {
           const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
           pv[0] = lo.x;
           pv[1] = lo.y;
+        } else {
+          pv[0] = scaled[(int64_t)i * a.npad];
         }
 #pragma unroll
         for (int32_t v = 0; v < V; ++v) {
-          q[i][v] = pv[v] * recip((double)prev_par[i].v[v]);
+          q[i][v] = pv[v] * (double)__builtin_amdgcn_rcpf(prev_par[i].v[v]);
           sum[v] += q[i][v];
         }
       }
@@ -464,13 +566,11 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
         for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] = (float)(q[i][v] * sum[v]);
     }
-    if (a.store_v2f) {
-      float* v2f_par = arena + a.f_in[2 * k];
-      float* v2f_own = arena + a.f_in[2 * k + 1];
+    if (a.store_full) {
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i) storev<V>(v2f_par, t * D0 + i, col, to_f_par[i]);
+      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, to_f_par[i]);
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j) storev<V>(v2f_own, t * S + j, col, to_f_own[j]);
+      for (int32_t j = 0; j < S; ++j) storev<V>(ptr.v2f_own, t * S + j, col, to_f_own[j]);
     }
     // factor contractions
     fv<V> new_par[D0], new_own[S];
@@ -489,10 +589,12 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
           new_own[j].v[v] = fmaf(cv, to_f_par[i].v[v], new_own[j].v[v]);
         }
       }
+    if (a.store_full) {
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) storev<V>(f2v_par, t * D0 + i, col, new_par[i]);
+      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.f2v_par, t * D0 + i, col, new_par[i]);
+    }
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) storev<V>(f2v_own, t * S + j, col, new_own[j]);
+    for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
     // fold into the partial product for the parent's next combine
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i)
@@ -508,6 +610,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
           pe[i][v] += de;
         }
     }
+    ptr = ptr_next;
+    cur = nxt;
   }
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
@@ -522,9 +626,12 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
       *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(pm[s][2], pm[s][3]);
       *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(pe[s][0], pe[s][1], pe[s][2], pe[s][3]);
-    } else {
+    } else if constexpr (V == 2) {
       *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
       *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(pe[s][0], pe[s][1]);
+    } else {
+      a.part_mant[row] = pm[s][0];
+      a.part_exp[row] = pe[s][0];
     }
   }
 }
