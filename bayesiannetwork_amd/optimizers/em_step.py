@@ -123,25 +123,31 @@ class FlatModel:
 
 def reduce_statistics(machine, flat_sums: torch.Tensor, ll, sharded: bool):
     """All-reduce (SUM) of [expected-count sums, log-likelihood sum, observation count] over the
-    ranks of torch.distributed; identity when not sharded.  Returns (sums, ll, total N)."""
+    ranks of torch.distributed; identity when not sharded.  Returns (sums, ll, total N).
+    Nothing here makes the host wait for the device when ``ll`` is a tensor: the packed buffer
+    is assembled with device-side copies and fills only."""
     n_local = float(max(machine.num_observations, 1))
     dist = torch.distributed
     if not (sharded and dist.is_available() and dist.is_initialized()):
         return flat_sums, ll, n_local
     avg = machine.settings.average_log_likelihood
+    total = flat_sums.numel()
+    packed = torch.empty(total + 2, dtype=torch.float64, device=flat_sums.device)
+    packed[:total].copy_(flat_sums)
     if isinstance(ll, torch.Tensor):
-        ll_sum = ll.reshape(1).double() * (n_local if avg else 1.0)
+        packed[total : total + 1].copy_(ll.reshape(1))
+        if avg:
+            packed[total : total + 1].mul_(n_local)
     else:
-        ll_sum = torch.tensor([(ll * n_local) if avg else ll], dtype=torch.float64, device=flat_sums.device)
-    packed = torch.cat([flat_sums, ll_sum.to(flat_sums.device),
-                        torch.tensor([n_local], dtype=torch.float64, device=flat_sums.device)])
+        packed[total : total + 1].fill_((ll * n_local) if avg else ll)
+    packed[total + 1 :].fill_(n_local)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-    n_total = packed[-1]
-    ll_out = packed[-2] / n_total if avg else packed[-2]
+    n_total = packed[total + 1]
+    ll_out = packed[total] / n_total if avg else packed[total]
     if not isinstance(ll, torch.Tensor):
         ll_out = ll_out.item()
         n_total = n_total.item()
-    return packed[:-2], ll_out, n_total
+    return packed[:total], ll_out, n_total
 
 
 def normalise(p_conditional: torch.Tensor) -> torch.Tensor:

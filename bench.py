@@ -30,6 +30,24 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
+def pmc_traffic(kernel_label: str):
+    """HBM bytes per launch of the kernel behind a profile label, from the committed rocprofv3
+    --pmc summary (tools/pmc_traffic.sh; FETCH_SIZE / WRITE_SIZE passes of this same command).
+    None when no summary covers the kernel."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    stem = {"leaf_family": "bn::leaf_family_p1", "factor_pass": "bn::factor_p", "em_counts": "bn::em_p",
+            "variable_pass": "bn::variable_small_fast", "wide_combine": "bn::wide_combine_fast",
+            "evidence_scatter": "bn::evidence_scatter", "log_likelihood": "bn::ll_partial"}.get(
+        kernel_label.split("[")[0])
+    if stem is None:
+        return None
+    hits = [v for k, v in table.items() if k.startswith(stem)]
+    return max(h["hbm_bytes_per_launch"] for h in hits) if hits else None
+
+
 def build_model(ts, model: str, num_pixels: int = 784):
     from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
 
@@ -117,7 +135,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -149,7 +167,8 @@ def main():
         opt = EmBatchOptimizer(
             network, factory,
             EmBatchOptimizerSettings(learning_rate=0.1, num_epochs=1, regularization=0.01,
-                                     sharded=world > 1, deferred_logging=True),
+                                     sharded=world > 1 or bool(os.environ.get("BN_BENCH_FORCE_SHARDED")),
+                                     deferred_logging=True),
             logger)
         opt.optimize(_Batches([batches[i % 2] for i in range(steps)], n * steps))
 
@@ -188,7 +207,7 @@ def main():
             avg_s = dom["total_ms"] / dom["launches"] / 1e3
             achieved = dom["alg_bytes"] / avg_s / 1e9
             roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_s * 1e3,
+                            frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dom["kernel"]), avg_launch_ms=avg_s * 1e3,
                             alg_bytes_per_launch=dom["alg_bytes"])
         out = {
             "metric": "evidence samples/sec (sum-product infer + EM step), MNIST 784-leaf latent model",
@@ -224,7 +243,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, 2000, 3, iters)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -1,0 +1,48 @@
+"""Turn the two rocprofv3 --pmc passes of tools/pmc_traffic.sh into bytes per launch per kernel.
+
+Counter units and gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and
+WRITE_SIZE are in KiB; WRITE_SIZE is exact for streaming stores; FETCH_SIZE reports half of
+the bytes of a 16-byte-per-lane coalesced streaming read and is doubled for those kernels.
+Calibrated here on kernels whose reads are known exactly (N = 60 000, 784 families):
+  em_p1_fast<10,2>     16 B/lane loads, 12 float rows: expected 2258 MB, raw counter 1132 MB -> x2
+  evidence_scatter      4 B/lane loads:                 expected  376 MB, raw counter  376 MB -> x1
+  leaf_family_p1<..,2>  8 B/lane loads:                 expected  800 MB, raw counter  786 MB -> x1
+so the doubling is applied only to kernels that load 16 bytes per lane."""
+import csv, glob, json, re, sys
+from collections import defaultdict
+
+out_dir, dest = sys.argv[1], sys.argv[2]
+
+
+def per_kernel(counter):
+    path = glob.glob(f"{out_dir}/{counter}/*/*counter_collection.csv")[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+result = {}
+for name in sorted(set(fetch) | set(write)):
+    if "bn::" not in name:
+        continue
+    f = fetch.get(name, [0.0])
+    w = write.get(name, [0.0])
+    short = re.sub(r"\(.*", "", name).replace("void ", "")
+    narrow = ("evidence_scatter" in short or "ll_partial" in short or "generic" in short or "gather_rows" in short
+              or "family_marginal" in short or re.search(r"leaf_family_p1<.*, [12]>", short) is not None)
+    factor = 1.0 if narrow else 2.0
+    result[short] = dict(
+        launches=len(f),
+        fetch_correction=factor,
+        fetch_bytes_per_launch=factor * 1024.0 * sum(f) / len(f),
+        write_bytes_per_launch=1024.0 * sum(w) / len(w),
+        fetch_raw_kib=sum(f) / len(f),
+    )
+    result[short]["hbm_bytes_per_launch"] = result[short]["fetch_bytes_per_launch"] + result[short]["write_bytes_per_launch"]
+json.dump(result, open(dest, "w"), indent=1)
+for k, v in result.items():
+    print(f"{k:60s} launches {v['launches']:4d}  fetch {v['fetch_bytes_per_launch'] / 1e6:10.1f} MB  write {v['write_bytes_per_launch'] / 1e6:10.1f} MB")
