@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "kernels_dense.h"
 #include "kernels_fast.h"
 #include "kernels_wide.h"
 #include "plan.h"
@@ -312,11 +313,34 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
       }
       return 1;
     }
-    if (g.num_inputs * g.num_states > 12) return 0;  // per-lane state would not fit the register budget
-    VarSmallFn fn = var_small_lookup(g.num_inputs, g.num_states);
-    if (!fn) return 0;
-    hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K,
-                       p.ntiles, fresh);
+    if (g.num_inputs > 4) return 0;
+    VarSmallFn fn = g.num_inputs * g.num_states <= 12 ? var_small_lookup(g.num_inputs, g.num_states) : nullptr;
+    if (fn) {
+      // whole node in registers
+      hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c,
+                         K, p.ntiles, fresh);
+      return launch_ok() ? 1 : -1;
+    }
+    // many states (or a shape without a register-resident instance): stream state by state
+    const dim3 grid(wave_blocks((int64_t)K * p.ntiles));
+    switch (g.num_inputs) {
+      case 1:
+        hipLaunchKernelGGL(variable_big_fast<1>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+                           p.ntiles, fresh);
+        break;
+      case 2:
+        hipLaunchKernelGGL(variable_big_fast<2>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+                           p.ntiles, fresh);
+        break;
+      case 3:
+        hipLaunchKernelGGL(variable_big_fast<3>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+                           p.ntiles, fresh);
+        break;
+      default:
+        hipLaunchKernelGGL(variable_big_fast<4>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+                           p.ntiles, fresh);
+        break;
+    }
     return launch_ok() ? 1 : -1;
   }
 }
@@ -405,7 +429,16 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 2) {
-      FactorP1Fn fn = factor_p1_lookup(g.dims[0], g.dims[1]);
+      const int32_t d0 = g.dims[0], sv = g.dims[1];
+      if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
+        // dense contraction on the matrix cores, one workgroup per (node, tile)
+        const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
+        FactorP1Fn dense = d0 == 64 ? (sv == 64 ? factor_p1_mfma<64, 64> : factor_p1_mfma<64, 32>)
+                                    : (sv == 64 ? factor_p1_mfma<32, 64> : factor_p1_mfma<32, 32>);
+        hipLaunchKernelGGL(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+        return launch_ok() ? 1 : -1;
+      }
+      FactorP1Fn fn = factor_p1_lookup(d0, sv);
       if (!fn) return 0;
       hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;
@@ -434,6 +467,14 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, d
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 2) {
+      const int32_t d0 = g.dims[0], sv = g.dims[1];
+      if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
+        EmP1Fn dense = d0 == 64 ? (sv == 64 ? em_p1_mfma<64, 64> : em_p1_mfma<64, 32>)
+                                : (sv == 64 ? em_p1_mfma<32, 64> : em_p1_mfma<32, 32>);
+        hipLaunchKernelGGL(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
+                           p.ntiles, nchunks, partial);
+        return launch_ok() ? 1 : -1;
+      }
       EmP1Fn fn = em_p1_lookup(g.dims[0], g.dims[1]);
       if (!fn) return 0;
       hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);

@@ -1,0 +1,308 @@
+// High-cardinality (32 / 64 state) single-parent families: the two factor contractions and
+// the EM count matrix are real GEMMs and run on the matrix cores with the exact-float32
+// instruction v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain in k order, so numerics match
+// the VALU kernels); the variable pass for many-state nodes streams state by state.
+//
+// The tile layout [tile][state][256 observations] is already the operand shape MFMA wants:
+// with OUTPUT^T[state_out][obs] = W[state_out][state_in] * MSG^T[state_in][obs]
+//   B operand  lane l holds MSG^T[k = l>>5][j = l&31]  -> 32 consecutive observations of one
+//              message row per half-wave: whole 128-byte lines straight from HBM,
+//   A operand  lane l holds W[i = l&31][k = l>>5]      -> the CPT (or its transpose), staged
+//              once per workgroup in LDS with a 65-float row pitch (conflict-free both ways),
+//   D          column = observation, rows = output states -> each accumulator register is
+//              stored as 128-byte runs of consecutive observations.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_fast.h"
+
+namespace bn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int32_t kCptPitch = 65;  // LDS row pitch (floats) for a <= 64-column CPT
+
+__device__ __forceinline__ int32_t mfma_row(int32_t reg, int32_t lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+// ---------------------------------------------------------------------------------
+// Factor pass, one parent (D0 states) and own variable (S states), D0, S in {32, 64}.
+// One workgroup (4 waves) per (node, tile); wave w owns observations [64w, 64w+64).
+//   to own variable  out_own^T[b][n] = sum_a cpt[a][b] * in_par^T[a][n]
+//   to parent        out_par^T[a][n] = sum_b cpt[a][b] * in_own^T[b][n]
+template <int D0, int S>
+__global__ void __launch_bounds__(256) factor_p1_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
+                                                     const int64_t* __restrict__ in_off,
+                                                     const int64_t* __restrict__ out_off,
+                                                     const int64_t* __restrict__ cpt_off, int32_t K,
+                                                     int64_t ntiles) {
+  __shared__ float w_lds[D0 * kCptPitch];
+  const int64_t item = blockIdx.x;
+  const int32_t k = (int32_t)(item / ntiles);
+  const int64_t t = item % ntiles;
+  if (k >= K) return;
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t half = lane >> 5, col = lane & 31;
+
+  const float* cpt = cpts + cpt_off[k];
+  for (int32_t e = threadIdx.x; e < D0 * S; e += 256) w_lds[(e / S) * kCptPitch + (e % S)] = cpt[e];
+  __syncthreads();
+
+  const float* in_par = arena + in_off[2 * k] + t * D0 * kTile + wave * 64;
+  const float* in_own = arena + in_off[2 * k + 1] + t * S * kTile + wave * 64;
+  float* out_par = arena + out_off[2 * k] + t * D0 * kTile + wave * 64;
+  float* out_own = arena + out_off[2 * k + 1] + t * S * kTile + wave * 64;
+
+  // ---- to own variable: i = b (S/32 tiles), k = a (D0/2 steps), j = observation (2 tiles)
+  {
+    f32x16 acc[S / 32][2];
+#pragma unroll
+    for (int32_t it = 0; it < S / 32; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+#pragma unroll 8
+    for (int32_t ks = 0; ks < D0 / 2; ++ks) {
+      const int32_t a = 2 * ks + half;
+      float bfrag[2];
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt) bfrag[jt] = in_par[(int64_t)a * kTile + 32 * jt + col];
+#pragma unroll
+      for (int32_t it = 0; it < S / 32; ++it) {
+        const float afrag = w_lds[a * kCptPitch + 32 * it + col];  // W[i=b][k=a] = cpt[a][b]
+#pragma unroll
+        for (int32_t jt = 0; jt < 2; ++jt)
+          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int32_t it = 0; it < S / 32; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r)
+          out_own[(int64_t)(32 * it + mfma_row(r, lane)) * kTile + 32 * jt + col] = acc[it][jt][r];
+  }
+  // ---- to parent: i = a (D0/32 tiles), k = b (S/2 steps), j = observation
+  {
+    f32x16 acc[D0 / 32][2];
+#pragma unroll
+    for (int32_t it = 0; it < D0 / 32; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+#pragma unroll 8
+    for (int32_t ks = 0; ks < S / 2; ++ks) {
+      const int32_t b = 2 * ks + half;
+      float bfrag[2];
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt) bfrag[jt] = in_own[(int64_t)b * kTile + 32 * jt + col];
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 32; ++it) {
+        const float afrag = w_lds[(32 * it + col) * kCptPitch + b];  // W[i=a][k=b] = cpt[a][b]
+#pragma unroll
+        for (int32_t jt = 0; jt < 2; ++jt)
+          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int32_t it = 0; it < D0 / 32; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r)
+          out_par[(int64_t)(32 * it + mfma_row(r, lane)) * kTile + 32 * jt + col] = acc[it][jt][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// EM count matrix for the same families: stat[a][b] = sum_n in_par[n][a] * in_own[n][b]
+// (the CPT factor is applied by em_finalize) = a [D0 x N] x [N x S] GEMM with the
+// observations as the k dimension.  One workgroup per (node, chunk of tiles); 64 observations
+// of both messages are staged in LDS per step (coalesced 16-byte loads, 65-float pitch), the
+// four waves own the four 32x32 quadrants of the count matrix (D0 = S = 64) or split it
+// accordingly.  Padding observations are zeroed while staging.
+template <int D0, int S>
+__global__ void __launch_bounds__(256) em_p1_mfma(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                 const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
+                                                 int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
+  __shared__ float par_lds[D0 * kCptPitch];
+  __shared__ float own_lds[S * kCptPitch];
+  const int32_t k = blockIdx.x / nchunks;
+  const int32_t chunk = blockIdx.x % nchunks;
+  if (k >= K) return;
+  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t half = lane >> 5, col = lane & 31;
+  constexpr int32_t kQuads = (D0 / 32) * (S / 32);   // 32x32 output tiles
+  constexpr int32_t kPerWave = (kQuads + 3) / 4;     // tiles per wave
+
+  const float* in_par = arena + in_off[2 * k];
+  const float* in_own = arena + in_off[2 * k + 1];
+  const int64_t per = (ntiles + nchunks - 1) / nchunks;
+  const int64_t t0 = chunk * per;
+  const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
+
+  f32x16 acc[kPerWave];
+#pragma unroll
+  for (int32_t q = 0; q < kPerWave; ++q)
+#pragma unroll
+    for (int32_t r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  for (int64_t t = t0; t < t1; ++t) {
+    for (int32_t quarter = 0; quarter < 4; ++quarter) {
+      const int64_t n0 = t * kTile + quarter * 64;
+      if (n0 >= N) break;
+      __syncthreads();
+      // stage [rows][64 observations] of both messages; thread -> (row, 4 observations)
+      for (int32_t e = threadIdx.x; e < D0 * 16; e += 256) {
+        const int32_t row = e >> 4, c4 = (e & 15) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(in_par + (t * D0 + row) * kTile + quarter * 64 + c4);
+        float* dst = par_lds + row * kCptPitch + c4;
+        dst[0] = n0 + c4 + 0 < N ? x.x : 0.f;
+        dst[1] = n0 + c4 + 1 < N ? x.y : 0.f;
+        dst[2] = n0 + c4 + 2 < N ? x.z : 0.f;
+        dst[3] = n0 + c4 + 3 < N ? x.w : 0.f;
+      }
+      for (int32_t e = threadIdx.x; e < S * 16; e += 256) {
+        const int32_t row = e >> 4, c4 = (e & 15) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(in_own + (t * S + row) * kTile + quarter * 64 + c4);
+        float* dst = own_lds + row * kCptPitch + c4;
+        dst[0] = x.x;
+        dst[1] = x.y;
+        dst[2] = x.z;
+        dst[3] = x.w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int32_t q = 0; q < kPerWave; ++q) {
+        const int32_t quad = wave * kPerWave + q;
+        if (quad < kQuads) {
+          const int32_t it = quad / (S / 32), jt = quad % (S / 32);
+#pragma unroll 8
+          for (int32_t ks = 0; ks < 32; ++ks) {
+            const int32_t n = 2 * ks + half;
+            const float afrag = par_lds[(32 * it + col) * kCptPitch + n];  // A[i=a][k=n]
+            const float bfrag = own_lds[(32 * jt + col) * kCptPitch + n];  // B[k=n][j=b]
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int32_t q = 0; q < kPerWave; ++q) {
+    const int32_t quad = wave * kPerWave + q;
+    if (quad < kQuads) {
+      const int32_t it = quad / (S / 32), jt = quad % (S / 32);
+#pragma unroll
+      for (int32_t r = 0; r < 16; ++r) {
+        const int32_t a = 32 * it + mfma_row(r, lane), b = 32 * jt + col;
+        partial[(cpt_off[k] + (int64_t)a * S + b) * nchunks + chunk] = (double)acc[q][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Variable pass for nodes with many states and a small fan-in I (<= 4): one wave per
+// (node, tile), four observations per lane, states streamed one at a time (products are per
+// state; only the normalisers couple states).  Pass 1 accumulates the normalisers, pass 2
+// re-reads the inputs (mostly from L2 / Infinity Cache) and writes the normalised messages.
+// Same quantities as variable_pass_generic.
+template <int I>
+__global__ void __launch_bounds__(256) variable_big_fast(float* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                        const int64_t* __restrict__ out_off,
+                                                        const int64_t* __restrict__ c_off, int32_t K, int32_t S,
+                                                        int64_t ntiles, int32_t fresh) {
+  int32_t k, lane;
+  int64_t t;
+  if (!wave_item((int64_t)K * ntiles, ntiles, k, t, lane)) return;
+  const float uniform = 1.0f / (float)S;
+  const float* src[I];
+  float* dst[I];
+  bool skip[I];
+#pragma unroll
+  for (int32_t i = 0; i < I; ++i) {
+    const int64_t o = out_off[(int64_t)k * I + i];
+    src[i] = arena + in_off[(int64_t)k * I + i];
+    dst[i] = o >= 0 ? arena + o : nullptr;
+    skip[i] = fresh && o >= 0;
+  }
+
+  double sums[I][4];
+  double z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int32_t i = 0; i < I; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) sums[i][v] = 0.0;
+
+  for (int32_t s = 0; s < S; ++s) {
+    f4 in[I];
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) in[i] = skip[i] ? f4{{uniform, uniform, uniform, uniform}} : load4(src[i], t * S + s, lane);
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      double loo[I];
+      double pre = 1.0;
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) {
+        loo[i] = pre;
+        pre *= (double)in[i].v[v];
+      }
+      z[v] += pre;
+      double suf = 1.0;
+#pragma unroll
+      for (int32_t i = I - 1; i >= 0; --i) {
+        sums[i][v] += loo[i] * suf;
+        suf *= (double)in[i].v[v];
+      }
+    }
+  }
+  {
+    f4 c;
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      int e = 0;
+      const double m = frexp(z[v], &e);
+      c.v[v] = (float)((double)e * 0.6931471805599453 + (double)logf((float)m));
+    }
+    store4(arena + c_off[k], t, lane, c);
+  }
+#pragma unroll
+  for (int32_t v = 0; v < 4; ++v) {
+#pragma unroll
+    for (int32_t i = 0; i < I - 1; ++i) sums[i][v] = 1.0 / sums[i][v];
+    sums[I - 1][v] = 1.0 / z[v];  // the message to the local factor is normalised by the full product
+  }
+  for (int32_t s = 0; s < S; ++s) {
+    f4 in[I];
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) in[i] = skip[i] ? f4{{uniform, uniform, uniform, uniform}} : load4(src[i], t * S + s, lane);
+    f4 out[I];
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      double loo[I];
+      double pre = 1.0;
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) {
+        loo[i] = pre;
+        pre *= (double)in[i].v[v];
+      }
+      double suf = 1.0;
+#pragma unroll
+      for (int32_t i = I - 1; i >= 0; --i) {
+        out[i].v[v] = (float)(loo[i] * suf * sums[i][v]);
+        suf *= (double)in[i].v[v];
+      }
+    }
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i)
+      if (dst[i]) store4(dst[i], t * S + s, lane, out[i]);
+  }
+}
+
+}  // namespace bn

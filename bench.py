@@ -77,6 +77,50 @@ def build_model(ts, model: str, num_pixels: int = 784):
     return builder.build(), ys
 
 
+def build_deep_tree(ts, depth: int = 6, states: int = 64):
+    """BASELINE.json configs[4]: balanced binary tree of 64-state hidden nodes (2^depth - 1 of
+    them) with one observed 64-state leaf under every hidden leaf; CPTs [64] / [64, 64]."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+
+    gen = torch.Generator().manual_seed(0)
+
+    def rand_cpt(shape):
+        p = torch.rand(shape, generator=gen, dtype=torch.float64)
+        p = (p / p.sum(dim=-1, keepdim=True)).to(ts.dtype)
+        return (p / p.sum(dim=-1, keepdim=True)).to(ts.device)
+
+    root = Node(rand_cpt((states,)), name="H0")
+    builder = BayesianNetworkBuilder().add_node(root)
+    frontier, count = [root], 1
+    for _ in range(depth - 1):
+        nxt = []
+        for parent in frontier:
+            for _ in range(2):
+                node = Node(rand_cpt((states, states)), name=f"H{count}")
+                count += 1
+                builder.add_node(node, parents=parent)
+                nxt.append(node)
+        frontier = nxt
+    leaves = []
+    for i, parent in enumerate(frontier):
+        leaf = Node(rand_cpt((states, states)), name=f"Y{i}")
+        builder.add_node(leaf, parents=parent)
+        leaves.append(leaf)
+    return builder.build(), leaves
+
+
+def one_hot_evidence(ts, n, nodes, seed, device):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+
+    gen = torch.Generator().manual_seed(seed)
+    data = []
+    for node in nodes:
+        idx = torch.randint(0, node.num_states, (n,), generator=gen)
+        e = torch.nn.functional.one_hot(idx, node.num_states).to(ts.dtype) * (1 - 1e-6) + 5e-7
+        data.append(e.to(device).contiguous())
+    return Evidence(data, ts)
+
+
 def synthetic_evidence(ts, n, num_pixels, seed, device):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
 
@@ -124,8 +168,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=60000, help="observations per GPU per step")
-    ap.add_argument("--model", choices=["c3a", "c3b"], default="c3a")
+    ap.add_argument("--batch", type=int, default=None, help="observations per GPU per step")
+    ap.add_argument("--model", choices=["c3a", "c3b", "c5"], default="c3a")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -150,11 +194,15 @@ def main():
 
     ts = TorchSettings(device="cuda", dtype=args.dtype)
     device = torch.device("cuda", local_rank)
-    network, ys = build_model(ts, args.model)
+    n = args.batch or (131072 if args.model == "c5" else 60000)
     iters = 10 if args.model == "c3b" else None
-    n = args.batch
     # two distinct resident batches, alternated, so no step re-reads the evidence it just used
-    batches = [synthetic_evidence(ts, n, len(ys), 1 + 17 * rank + b, device) for b in range(2)]
+    if args.model == "c5":
+        network, ys = build_deep_tree(ts)
+        batches = [one_hot_evidence(ts, n, ys, 1 + 17 * rank + b, device) for b in range(2)]
+    else:
+        network, ys = build_model(ts, args.model)
+        batches = [synthetic_evidence(ts, n, len(ys), 1 + 17 * rank + b, device) for b in range(2)]
 
     def factory(net):
         return HipSpaInferenceMachine(
@@ -223,8 +271,9 @@ def main():
             "dtype": "f32" if args.dtype == "float32" else "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("Q(10)->784xY(2) latent-class model" if args.model == "c3a"
-                             else "Q(10)->F1,F2(2)->784xY(2|F1,F2) loopy model")
+                "workload": {"c3a": "Q(10)->784xY(2) latent-class model",
+                             "c3b": "Q(10)->F1,F2(2)->784xY(2|F1,F2) loopy model",
+                             "c5": "depth-6 binary tree of 64-state hidden nodes + 32 observed 64-state leaves"}[args.model]
                 + f", EM step (T={t_used} flooding iterations + ll + expected counts + M-step)",
                 "batch_per_gpu": n,
                 "global_batch": n * world,
@@ -240,7 +289,7 @@ def main():
                 for k in kernels
             ],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model != "c5":
             out["cpu_baseline"] = cpu_baseline(args.model, 2000, 3, iters)
         print(json.dumps(out))
     if torch.distributed.is_initialized():
