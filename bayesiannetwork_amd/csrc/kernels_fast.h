@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) variable_small_fast(float* __restrict__ a
 // ---------------------------------------------------------------------------------
 // EM expected counts, one parent (D0) + own variable (S), or no parent (D0 = 1, the
 // parent message is the constant 1): per lane running sums of in_parent[a] * in_own[b]
-// over the observations of the wave's tile range, then a wave reduction.  The CPT factor
+// over the observations of the wave's tile range (double running sums), then a wave reduction.  The CPT factor
 // and the sum over chunks are applied by em_finalize.
 template <int D0, int S, bool HAS_PARENT>
 __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
@@ -303,11 +303,11 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
   const int64_t t0 = chunk * per;
   const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
 
-  float acc[D0][S];
+  double acc[D0][S];
 #pragma unroll
   for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) acc[i][j] = 0.f;
+    for (int32_t j = 0; j < S; ++j) acc[i][j] = 0.0;
 
   for (int64_t t = t0; t < t1; ++t) {
     f4 a[D0], b[S];
@@ -324,12 +324,12 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
     const int64_t n0 = t * kTile + lane * 4;
 #pragma unroll
     for (int32_t v = 0; v < 4; ++v) {
-      const float live = (n0 + v < N) ? 1.f : 0.f;
+      const double live = (n0 + v < N) ? 1.0 : 0.0;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
-        const float av = a[i].v[v] * live;
+        const double av = (double)a[i].v[v] * live;
 #pragma unroll
-        for (int32_t j = 0; j < S; ++j) acc[i][j] = fmaf(av, b[j].v[v], acc[i][j]);
+        for (int32_t j = 0; j < S; ++j) acc[i][j] = fma(av, (double)b[j].v[v], acc[i][j]);
       }
     }
   }
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
   for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
     for (int32_t j = 0; j < S; ++j) {
-      double x = (double)acc[i][j];
+      double x = acc[i][j];
 #pragma unroll
       for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (lane == 0) partial[(cpt_off[k] + i * S + j) * nchunks + chunk] = x;
@@ -361,13 +361,13 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
   const int64_t t0 = chunk * per;
   const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
 
-  float acc[D0][D1][S];
+  double acc[D0][D1][S];
 #pragma unroll
   for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
     for (int32_t j = 0; j < D1; ++j)
 #pragma unroll
-      for (int32_t l = 0; l < S; ++l) acc[i][j][l] = 0.f;
+      for (int32_t l = 0; l < S; ++l) acc[i][j][l] = 0.0;
 
   for (int64_t t = t0; t < t1; ++t) {
     f4 a[D0], b[D1], c[S];
@@ -380,15 +380,15 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
     const int64_t n0 = t * kTile + lane * 4;
 #pragma unroll
     for (int32_t v = 0; v < 4; ++v) {
-      const float live = (n0 + v < N) ? 1.f : 0.f;
+      const double live = (n0 + v < N) ? 1.0 : 0.0;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
-        const float av = a[i].v[v] * live;
+        const double av = (double)a[i].v[v] * live;
 #pragma unroll
         for (int32_t j = 0; j < D1; ++j) {
-          const float ab = av * b[j].v[v];
+          const double ab = av * (double)b[j].v[v];
 #pragma unroll
-          for (int32_t l = 0; l < S; ++l) acc[i][j][l] = fmaf(ab, c[l].v[v], acc[i][j][l]);
+          for (int32_t l = 0; l < S; ++l) acc[i][j][l] = fma(ab, (double)c[l].v[v], acc[i][j][l]);
         }
       }
     }
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
     for (int32_t j = 0; j < D1; ++j)
 #pragma unroll
       for (int32_t l = 0; l < S; ++l) {
-        double x = (double)acc[i][j][l];
+        double x = acc[i][j][l];
 #pragma unroll
         for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
         if (lane == 0) partial[(cpt_off[k] + (i * D1 + j) * S + l) * nchunks + chunk] = x;

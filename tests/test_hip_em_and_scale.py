@@ -1,0 +1,125 @@
+"""GPU: the EM optimizers driving the HIP machine against the reference's post-step CPTs, and
+size-independent properties at the benchmark's full batch size."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Fixture, em_fixture_names
+
+pytestmark = pytest.mark.gpu
+
+
+class Loader:
+    def __init__(self, batches, total):
+        self._batches, self.num_observations = batches, total
+
+    def __len__(self):
+        return len(self._batches)
+
+    def __iter__(self):
+        return iter(self._batches)
+
+
+def _factory(fx, ts, observed, n):
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    settings = SpaInferenceMachineSettings(ts, True, num_iterations=fx.meta["num_iterations"],
+                                           allow_loops=fx.meta["allow_loops"])
+    return lambda net: HipSpaInferenceMachine(settings, net, observed, n)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+@pytest.mark.parametrize("name", em_fixture_names())
+def test_em_optimizers_on_gpu_reproduce_reference(name, deferred):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.optimizers import (
+        EmBatchOptimizer,
+        EmBatchOptimizerSettings,
+        EmOptimizer,
+        EmOptimizerSettings,
+        OptimizerLogger,
+    )
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    em = json.loads(str(fx["em/meta"]))
+    if deferred and em["kind"] == "full":
+        pytest.skip("deferred logging is a mini-batch optimizer option")
+    ts = TorchSettings(device="cuda", dtype=fx.meta["dtype"])
+    network, observed, _ = fx.build(ts)
+    evidence = Evidence(fx.evidence_tensors("cuda"), ts)
+    logger = OptimizerLogger()
+    if em["kind"] == "full":
+        EmOptimizer(network, _factory(fx, ts, observed, fx.meta["N"]), EmOptimizerSettings(em["steps"]), logger).optimize(
+            evidence)
+        last = em["steps"] - 1
+    else:
+        b = em["batch"]
+        loader = Loader([evidence[0:b], evidence[b:2 * b]], fx.meta["N"])
+        EmBatchOptimizer(network, _factory(fx, ts, observed, b),
+                         EmBatchOptimizerSettings(em["learning_rate"], em["num_epochs"], em["regularization"],
+                                                  deferred_logging=deferred), logger).optimize(loader)
+        last = 2 * em["num_epochs"] - 1
+    # float32: three EM steps compound the inference rounding (and the reference's own float32 noise)
+    tol = dict(rtol=1e-9, atol=1e-13) if fx.dtype == torch.float64 else dict(rtol=1e-4, atol=2e-7)
+    for node in network.nodes:
+        np.testing.assert_allclose(node.cpt.cpu().numpy(), fx[f"em/step{last}/{node.name}"], err_msg=node.name, **tol)
+    np.testing.assert_allclose([log.ll for log in logger.logs], fx["em/ll"],
+                               rtol=1e-9 if fx.dtype == torch.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32"])
+def test_full_batch_size_properties(name):
+    """60 000 observations (the benchmark batch) made of the fixture's 24 rows repeated: every
+    2 500-fold copy must reproduce the fixture row's answer, marginals must be normalised, the
+    log-likelihood must equal the sum of the local normalisers and scale with the copies, and
+    EM counts must be the fixture's counts (means are invariant under replication)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    ts = TorchSettings(device="cuda", dtype="float32")
+    network, observed, by_name = fx.build(ts)
+    base = fx.meta["N"]
+    reps = 2500
+    n = base * reps
+    ev = [e.cuda().repeat(reps, 1).contiguous() for e in fx.evidence_tensors()]
+    machine = HipSpaInferenceMachine(
+        SpaInferenceMachineSettings(ts, False, num_iterations=fx.meta["num_iterations"], allow_loops=fx.meta["allow_loops"]),
+        network, observed, n)
+    machine.enter_evidence(Evidence(ev, ts))
+
+    small = HipSpaInferenceMachine(
+        SpaInferenceMachineSettings(ts, False, num_iterations=fx.meta["num_iterations"], allow_loops=fx.meta["allow_loops"]),
+        network, observed, base)
+    small.enter_evidence(Evidence([e.cuda() for e in fx.evidence_tensors()], ts))
+
+    q = by_name["Q"]
+    big_q = machine.infer_single_nodes([q])[0]
+    small_q = small.infer_single_nodes([q])[0]
+    assert torch.equal(big_q.view(reps, base, -1), small_q.expand(reps, -1, -1)), "replicated rows must be bit-identical"
+    assert torch.allclose(big_q.sum(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    y = by_name["Y391"]
+    fam = machine.infer_nodes_with_parents([y])[0]
+    assert torch.equal(fam[:base], small.infer_nodes_with_parents([y])[0])
+    if not fx.meta["allow_loops"]:
+        assert torch.allclose(fam.reshape(n, -1).sum(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+
+    ll_big, ll_small = machine.log_likelihood(), small.log_likelihood()
+    np.testing.assert_allclose(ll_big, reps * ll_small, rtol=1e-9)
+    c_total = sum(machine.local_log_likelihoods(node).double().sum().item() for node in (q, y))
+    assert np.isfinite(c_total)
+
+    counts_big = machine.expected_count_sums() / n
+    counts_small = small.expected_count_sums() / base
+    np.testing.assert_allclose(counts_big.cpu().numpy(), counts_small.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    for node, sums in zip(network.nodes, machine.split_counts(counts_big)):
+        key = f"truth/counts/{node.name}"
+        if key in fx:
+            # loopy iteration amplifies float32 rounding (the reference's own float32 run is off by 1.5e-4)
+            rtol = 2e-4 if fx.meta["allow_loops"] else 4e-5
+            np.testing.assert_allclose(sums.cpu().numpy(), fx[key], rtol=rtol, atol=1e-7)
