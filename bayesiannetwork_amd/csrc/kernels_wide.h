@@ -458,7 +458,36 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   const int32_t first = chunk * a.chunk_len;
   const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
   if (first >= last) return;
-  const double* scaled = a.scaled + t * kTile + col;
+  // the parent's scaled product for this lane's observations, as float mantissa + exponent
+  float pf_m[D0][V];
+  int32_t pf_e[D0][V];
+  {
+    const double* scaled = a.scaled + t * kTile + col;
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) {
+      double pv[V];
+      if constexpr (V == 4) {
+        const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
+        const double2 hi = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad + 2);
+        pv[0] = lo.x;
+        pv[1] = lo.y;
+        pv[2] = hi.x;
+        pv[3] = hi.y;
+      } else if constexpr (V == 2) {
+        const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
+        pv[0] = lo.x;
+        pv[1] = lo.y;
+      } else {
+        pv[0] = scaled[(int64_t)i * a.npad];
+      }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        int de = 0;
+        pf_m[i][v] = (float)frexp(pv[v], &de);
+        pf_e[i][v] = de < -4000 ? -4000 : de;
+      }
+    }
+  }
 
   LeafPtrs ptr = leaf_ptrs(arena, cpts, a, first);
   LeafState<S, V> cur = leaf_state<S, V>(ptr, a, t, col);
@@ -483,9 +512,9 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       fv<V> tfo[S];
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
-        const double inv = recip((double)cur.zp.v[v]);
+        const float inv = (float)recip((double)cur.zp.v[v]);
 #pragma unroll
-        for (int32_t j = 0; j < S; ++j) tfo[j].v[v] = (float)((double)cur.ev[j].v[v] * inv);
+        for (int32_t j = 0; j < S; ++j) tfo[j].v[v] = cur.ev[j].v[v] * inv;
       }
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
@@ -523,48 +552,34 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       }
       storev<V>(ptr.c, t, col, c);
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j)
+      for (int32_t v = 0; v < V; ++v) {
+        const float inv = (float)z[v];
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = (float)((double)cur.ev[j].v[v] * z[v]);
+        for (int32_t j = 0; j < S; ++j) to_f_own[j].v[v] = cur.ev[j].v[v] * inv;
+      }
     }
-    // wide parent: message to this factor = (P'/prev_par) normalised.  P' is re-read per family
-    // (shared by every wave working on this tile, so it comes from L2).  The reciprocal is a
-    // float one: this message only reaches the leaf, its rounding does not enter the wide product.
+    // wide parent: message to this factor = (P'/prev_par) normalised, in float: this message
+    // only reaches the leaf, its rounding never enters the wide product.  P' is held as a float
+    // mantissa and an exponent (<= 0, relative to the largest state), applied with ldexp after
+    // the division, so a state only vanishes when its quotient itself is below float range.
     fv<V> to_f_par[D0];
     {
-      double q[D0][V];
-      double sum[V];
+      float sum[V];
 #pragma unroll
-      for (int32_t v = 0; v < V; ++v) sum[v] = 0.0;
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i) {
-        double pv[V];
-        if constexpr (V == 4) {
-          const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
-          const double2 hi = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad + 2);
-          pv[0] = lo.x;
-          pv[1] = lo.y;
-          pv[2] = hi.x;
-          pv[3] = hi.y;
-        } else if constexpr (V == 2) {
-          const double2 lo = *reinterpret_cast<const double2*>(scaled + (int64_t)i * a.npad);
-          pv[0] = lo.x;
-          pv[1] = lo.y;
-        } else {
-          pv[0] = scaled[(int64_t)i * a.npad];
-        }
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          q[i][v] = pv[v] * (double)__builtin_amdgcn_rcpf(prev_par[i].v[v]);
-          sum[v] += q[i][v];
-        }
-      }
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) sum[v] = recip(sum[v]);
+      for (int32_t v = 0; v < V; ++v) sum[v] = 0.f;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] = (float)(q[i][v] * sum[v]);
+        for (int32_t v = 0; v < V; ++v) {
+          to_f_par[i].v[v] = ldexpf(pf_m[i][v] * __builtin_amdgcn_rcpf(prev_par[i].v[v]), pf_e[i][v]);
+          sum[v] += to_f_par[i].v[v];
+        }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) sum[v] = __builtin_amdgcn_rcpf(sum[v]);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] *= sum[v];
     }
     if (a.store_full) {
 #pragma unroll
