@@ -176,7 +176,10 @@ inline int prepare_fast(Plan& p) {
       w.uncovered = {w.I - 2, w.I - 1};
     }
     const int32_t n = (int32_t)w.covered.size();
-    const int64_t want = (4096 + p.ntiles - 1) / p.ntiles;
+    // about three rounds of resident waves (2 per SIMD x 1024 SIMDs) per launch: measured best on
+    // the 784-leaf model between 4 and 26 chunks
+    int64_t want = std::max<int64_t>(1, (6144 + p.ntiles) / (2 * p.ntiles));
+    if (getenv("BN_WIDE_CHUNKS")) want = atoi(getenv("BN_WIDE_CHUNKS"));
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
     w.chunk_len = (n + chunks - 1) / chunks;
     w.chunks = (n + w.chunk_len - 1) / w.chunk_len;
@@ -347,36 +350,31 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
 
 using LeafFamilyFn = void (*)(float*, const float*, LeafFamilyArgs);
 
-template <int D0, int V>
+constexpr int32_t kLeafVec = 2;  // observations per lane in the leaf-family kernel: 4 leaves one wave
+                                 // per SIMD, 1 doubles the per-family instruction overhead (measured)
+
+template <int D0, bool FULL>
 inline LeafFamilyFn leaf_family_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return leaf_family_p1<D0, SV, V>;
+    return leaf_family_p1<D0, SV, kLeafVec, FULL>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-template <int V>
+template <bool FULL>
 inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return leaf_family_for_s<DV, V>(s);
+    return leaf_family_for_s<DV, FULL>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
-}
-
-// observations per lane in the leaf-family kernel (2 measured fastest for both modes on the
-// 784-leaf model: 4 leaves one wave per SIMD, 1 doubles the per-family instruction overhead)
-inline int32_t leaf_vec(bool store_full) {
-  static const int32_t loop_vec = getenv("BN_LEAF_VEC_LOOP") ? atoi(getenv("BN_LEAF_VEC_LOOP")) : 2;
-  static const int32_t full_vec = getenv("BN_LEAF_VEC_FULL") ? atoi(getenv("BN_LEAF_VEC_FULL")) : 2;
-  return store_full ? full_vec : loop_vec;
 }
 
 template <typename T>
@@ -395,10 +393,9 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       auto it = st->fused.find((int32_t)fi);
       if (it != st->fused.end()) {
         WideNode& w = st->wide[it->second.wide_index];
-        const int32_t vec = leaf_vec(last_iteration != 0);
-        LeafFamilyFn fn = vec == 1   ? leaf_family_lookup<1>(g.dims[0], g.dims[1])
-                          : vec == 4 ? leaf_family_lookup<4>(g.dims[0], g.dims[1])
-                                     : leaf_family_lookup<2>(g.dims[0], g.dims[1]);
+        const int32_t vec = kLeafVec;
+        LeafFamilyFn fn = last_iteration ? leaf_family_lookup<true>(g.dims[0], g.dims[1])
+                                         : leaf_family_lookup<false>(g.dims[0], g.dims[1]);
         if (!fn) return -1;
         LeafFamilyArgs a;
         a.f_in = g.d_in;
@@ -416,7 +413,6 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
         a.ntiles = p.ntiles;
         a.fresh = fresh;
         a.prev_from_arrays = first_iteration;
-        a.store_full = last_iteration;
         hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / vec))), dim3(256), 0, s, arena, cpts, a);
         if (!launch_ok()) return -1;
         w.partials_valid = true;

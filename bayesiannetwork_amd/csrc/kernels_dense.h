@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) factor_p1_mfma(float* __restrict__ arena,
   const int32_t k = (int32_t)(item / ntiles);
   const int64_t t = item % ntiles;
   if (k >= K) return;
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int32_t half = lane >> 5, col = lane & 31;
 
   const float* cpt = cpts + cpt_off[k];
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) em_p1_mfma(const float* __restrict__ aren
   const int32_t k = blockIdx.x / nchunks;
   const int32_t chunk = blockIdx.x % nchunks;
   if (k >= K) return;
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int32_t half = lane >> 5, col = lane & 31;
   constexpr int32_t kQuads = (D0 / 32) * (S / 32);   // 32x32 output tiles
   constexpr int32_t kPerWave = (kQuads + 3) / 4;     // tiles per wave

@@ -45,7 +45,9 @@ __device__ __forceinline__ void store4(float* __restrict__ base, int64_t row, in
 
 // work item of this wave, or false if past the end.  items = K * ntiles, node-major.
 __device__ __forceinline__ bool wave_item(int64_t items, int64_t ntiles, int32_t& k, int64_t& t, int32_t& lane) {
-  const int32_t wave = threadIdx.x >> 6;
+  // readfirstlane tells the compiler the wave index is uniform: everything derived from it (node,
+  // tile, table offsets, CPT entries) then lives in scalar registers and scalar loads
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= items) return false;
@@ -290,7 +292,7 @@ template <int D0, int S, bool HAS_PARENT>
 __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
                                                  int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)K * nchunks) return;
   const int32_t k = (int32_t)(w / nchunks);
@@ -348,7 +350,7 @@ template <int D0, int D1, int S>
 __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
                                                  int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)K * nchunks) return;
   const int32_t k = (int32_t)(w / nchunks);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void store_partial(const WideArgs& a, int32_t chunk, 
 
 template <int S>
 __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict__ arena, WideArgs a) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)a.chunks * a.ntiles) return;
   const int32_t chunk = (int32_t)(w / a.ntiles);
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
 
 template <int S>
 __global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (t >= a.ntiles) return;
 
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ are
 
 template <int S>
 __global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena, WideArgs a) {
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)a.chunks * a.ntiles) return;
   const int32_t chunk = (int32_t)(w / a.ntiles);
@@ -327,10 +327,10 @@ struct LeafFamilyArgs {
   // first iteration of a bn_iterate call: the factor's previous message to the parent is read
   // from its array; later iterations rebuild it from the leaf's previous normaliser (see kernel)
   int32_t prev_from_arrays;
-  // last iteration of a bn_iterate call: write everything queries may read (both variable ->
-  // factor messages, the message to the parent, c = log z); otherwise only the loop state
-  int32_t store_full;
 };
+// Template flag FULL = last iteration of a bn_iterate call: write everything queries may read
+// (both variable -> factor messages, the message to the parent, c = log z); otherwise only the
+// loop state (message to the own variable, z).
 
 // 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
 // seed plus one Newton step.
@@ -432,11 +432,11 @@ __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const L
   return st;
 }
 
-template <int D0, int S, int V>
+template <int D0, int S, int V, bool FULL>
 __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      LeafFamilyArgs a) {
   constexpr int32_t kParts = 4 / V;
-  const int32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
   const int32_t part = (int32_t)(w % kParts);
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         const float zf = (float)z[v];
-        if (a.store_full) {
+        if (FULL) {
           int de = 0;
           const double mz = frexp(z[v], &de);
           c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
         for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] *= sum[v];
     }
-    if (a.store_full) {
+    if (FULL) {
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, to_f_par[i]);
 #pragma unroll
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
           new_own[j].v[v] = fmaf(cv, to_f_par[i].v[v], new_own[j].v[v]);
         }
       }
-    if (a.store_full) {
+    if (FULL) {
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.f2v_par, t * D0 + i, col, new_par[i]);
     }
