@@ -201,6 +201,13 @@ int reset_messages_t(bn::Plan& p, hipStream_t s) {
   return BN_OK;
 }
 
+// A leaf-family iteration that was only reduced (bn_em_statistics) is completed before anything
+// reads or changes messages, evidence or CPTs.
+int complete_pending(bn::Plan& p, hipStream_t s) {
+  if (bn::complete_pending_fast(p, s) < 0) return fail(BN_ERR_HIP, "launch of the leaf-family kernel failed");
+  return BN_OK;
+}
+
 // Observation slots that were reset but never received evidence get their uniform value now.
 int settle_observations(bn::Plan& p, hipStream_t s) {
   if (!p.obs_pending) return BN_OK;
@@ -212,6 +219,7 @@ int settle_observations(bn::Plan& p, hipStream_t s) {
 
 // Anything that reads message arrays directly needs them to hold real values.
 int materialize(bn::Plan& p, hipStream_t s) {
+  if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_observations(p, s)) return rc;
   if (!p.fresh) return BN_OK;
   int rc = p.dtype == BN_F32 ? fill_arrays<float>(p, 0, p.fill_messages, s)
@@ -221,7 +229,7 @@ int materialize(bn::Plan& p, hipStream_t s) {
 }
 
 template <typename T>
-int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
+int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t s) {
   T* arena = static_cast<T*>(p.arena);
   const T* cpts = static_cast<const T*>(p.cpts);
   const int32_t subs = p.tile / 64;
@@ -258,7 +266,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
         bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
         prof_begin(label, bytes, s);
       }
-      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, s);
+      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, reduce_last, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
       if (rc == 0) {
         bn::FactorDims fd = make_dims(g.dims);
@@ -278,13 +286,18 @@ int iterate_t(bn::Plan& p, int32_t iterations, hipStream_t s) {
 }
 
 template <typename T>
-int em_accumulate_t(bn::Plan& p, double* accum, hipStream_t s) {
+int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s) {
+  std::vector<const bn::FactorGroup*> reduced_groups;
   const T* arena = static_cast<const T*>(p.arena);
   const T* cpts = static_cast<const T*>(p.cpts);
   const int32_t nchunks = em_chunks(p);
   double* partial = p.scratch + kLlBlocks;
   for (auto& g : p.fgroups) {
     const int32_t K = (int32_t)g.nodes.size();
+    if (use_reduced && bn::em_is_reduced(p, (size_t)(&g - p.fgroups.data()))) {
+      reduced_groups.push_back(&g);  // finalised below, after the generic finalize has filled the rest
+      continue;
+    }
     prof_begin(flabel("em_counts", g), factor_bytes(p, g, true), s);
     int rc = bn::launch_em_fast<T>(p, g, arena, nchunks, partial, s);
     if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised EM kernel failed");
@@ -312,6 +325,12 @@ int em_accumulate_t(bn::Plan& p, double* accum, hipStream_t s) {
                      cpts, p.cpt_total, nchunks, accum);
   BN_LAUNCH_CHECK("em_finalize");
   prof_end(s);
+  for (const bn::FactorGroup* g : reduced_groups) {
+    prof_begin(flabel("em_counts(from leaf_family sums)", *g), 0.0, s);
+    if (bn::finalize_em_fast(p, (size_t)(g - p.fgroups.data()), accum, s) <= 0)
+      return fail(BN_ERR_HIP, "launch of em_finalize_slots failed");
+    prof_end(s);
+  }
   return BN_OK;
 }
 
@@ -458,6 +477,7 @@ int64_t bn_plan_device_bytes(const bn_plan* plan) { return plan ? plan->p.device
 int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = complete_pending(p, static_cast<hipStream_t>(stream))) return rc;
   BN_HIP_CHECK(hipMemcpyAsync(p.cpts, cpts_dev, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice,
                               static_cast<hipStream_t>(stream)));
   p.cpts_set = true;
@@ -477,6 +497,7 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   if (p.observed.empty()) return BN_OK;
   if (!evidence_dev) return fail(BN_ERR_INVALID, "evidence_dev is null");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
   const size_t count = p.observed.size();
   int32_t max_states = 1;
   for (size_t i = 0; i < count; ++i) {
@@ -517,8 +538,9 @@ int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
   bn::Plan& p = plan->p;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_observations(p, s)) return rc;
-  return p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, s) : iterate_t<double>(p, num_iterations, s);
+  return p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 0, s) : iterate_t<double>(p, num_iterations, 0, s);
 }
 
 int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* stream) {
@@ -622,7 +644,24 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream) {
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = materialize(p, s)) return rc;
-  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, s) : em_accumulate_t<double>(p, accum_dev, s);
+  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, false, s)
+                           : em_accumulate_t<double>(p, accum_dev, false, s);
+}
+
+int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
+                     void* stream) {
+  if (!plan || !ll_out_dev || !accum_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
+  bn::Plan& p = plan->p;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
+  if (int rc = settle_observations(p, s)) return rc;
+  int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 1, s) : iterate_t<double>(p, num_iterations, 1, s);
+  if (rc != BN_OK) return rc;
+  rc = bn_log_likelihood(plan, average, ll_out_dev, stream);
+  if (rc != BN_OK) return rc;
+  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
 }
 
 int bn_profile_enable(int32_t enabled) {

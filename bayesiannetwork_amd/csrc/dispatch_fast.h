@@ -21,6 +21,9 @@
 namespace bn {
 
 constexpr int32_t kMaxUncovered = 8;
+// observations per lane in the leaf-family kernel: 4 leaves one wave per SIMD, 1 doubles the
+// per-family instruction overhead (both measured slower on the 784-leaf model)
+constexpr int32_t kLeafVec = 2;
 
 struct WideNode {
   int32_t node = -1, vgroup = -1, vpos = -1;
@@ -40,6 +43,14 @@ struct FusedFamily {
   int32_t wide_index = -1;
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
+  float* z_state = nullptr;     // [K][npad] loop-state normalisers
+  float* em_partial = nullptr;  // [K][entries][slots], written by the reduce-mode kernel
+  int32_t slots = 0;
+  // the last iteration ran in reduce mode: stored messages are one iteration behind until
+  // complete_pending_fast re-runs it in full mode with these flags
+  bool pending = false;
+  int32_t pending_fresh = 0, pending_first = 0;
+  bool em_ready = false;  // em_partial holds the counts of the current state
 };
 
 struct FastState {
@@ -98,13 +109,20 @@ inline void release_fast(Plan& p) {
   for (auto& kv : st->fused) {
     if (kv.second.d_obs_off) (void)hipFree(kv.second.d_obs_off);
     if (kv.second.d_c_off) (void)hipFree(kv.second.d_c_off);
+    if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
+    if (kv.second.z_state) (void)hipFree(kv.second.z_state);
   }
   fast_states().erase(&p);
 }
 
 inline void invalidate_fast(Plan& p) {
-  if (FastState* st = fast_state(p))
+  if (FastState* st = fast_state(p)) {
     for (auto& w : st->wide) w.partials_valid = false;
+    for (auto& kv : st->fused) {
+      kv.second.pending = false;
+      kv.second.em_ready = false;
+    }
+  }
 }
 
 inline int prepare_fast(Plan& p) {
@@ -162,6 +180,13 @@ inline int prepare_fast(Plan& p) {
       handled[j] = 1;
     }
     if (!dev_upload(obs, &fam.d_obs_off, p.device_bytes) || !dev_upload(cs, &fam.d_c_off, p.device_bytes)) return -2;
+    fam.slots = (int32_t)(p.ntiles * (4 / kLeafVec));
+    const size_t em_elems = g.nodes.size() * (size_t)g.cpt_elems * fam.slots;
+    if (hipMalloc(reinterpret_cast<void**>(&fam.em_partial), em_elems * sizeof(float)) != hipSuccess) return -2;
+    p.device_bytes += (int64_t)(em_elems * sizeof(float));
+    if (hipMalloc(reinterpret_cast<void**>(&fam.z_state), g.nodes.size() * (size_t)p.npad * sizeof(float)) != hipSuccess)
+      return -2;
+    p.device_bytes += (int64_t)(g.nodes.size() * (size_t)p.npad * sizeof(float));
     st.fused[(int32_t)fi] = fam;
   }
   for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
@@ -350,36 +375,113 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
 
 using LeafFamilyFn = void (*)(float*, const float*, LeafFamilyArgs);
 
-constexpr int32_t kLeafVec = 2;  // observations per lane in the leaf-family kernel: 4 leaves one wave
-                                 // per SIMD, 1 doubles the per-family instruction overhead (measured)
 
-template <int D0, bool FULL>
+template <int D0, int MODE>
 inline LeafFamilyFn leaf_family_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return leaf_family_p1<D0, SV, kLeafVec, FULL>;
+    return leaf_family_p1<D0, SV, kLeafVec, MODE>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-template <bool FULL>
+template <int MODE>
 inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return leaf_family_for_s<DV, FULL>(s);
+    return leaf_family_for_s<DV, MODE>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
+inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, float* arena, const float* cpts,
+                              int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s) {
+  LeafFamilyFn fn = mode == kLeafFull     ? leaf_family_lookup<kLeafFull>(g.dims[0], g.dims[1])
+                    : mode == kLeafReduce ? leaf_family_lookup<kLeafReduce>(g.dims[0], g.dims[1])
+                                          : leaf_family_lookup<kLeafLoop>(g.dims[0], g.dims[1]);
+  if (!fn) return -1;
+  LeafFamilyArgs a;
+  a.f_in = g.d_in;
+  a.f_out = g.d_out;
+  a.cpt_off = g.d_cpt;
+  a.obs_off = fam.d_obs_off;
+  a.c_off = fam.d_c_off;
+  a.K = (int32_t)g.nodes.size();
+  a.chunks = w.chunks;
+  a.chunk_len = w.chunk_len;
+  a.part_mant = w.part_mant;
+  a.part_exp = w.part_exp;
+  a.scaled = w.scaled;
+  a.npad = p.npad;
+  a.ntiles = p.ntiles;
+  a.fresh = fresh;
+  a.prev_from_arrays = first_iteration;
+  a.N = p.N;
+  a.z_state = fam.z_state;
+  a.em_partial = fam.em_partial;
+  a.slots = fam.slots;
+  hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
+  if (!launch_ok()) return -1;
+  if (mode == kLeafReduce) {
+    fam.pending = true;
+    fam.pending_fresh = fresh;
+    fam.pending_first = first_iteration;
+    fam.em_ready = true;
+  } else {
+    fam.pending = false;
+    fam.em_ready = false;
+    w.partials_valid = true;
+  }
+  return 1;
+}
+
+// Re-run, in full mode, every leaf-family iteration that was only reduced.  Must precede
+// anything that reads or changes messages, evidence or CPTs.
+inline int complete_pending_fast(Plan& p, hipStream_t s) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0) return 0;
+  for (auto& kv : st->fused) {
+    FusedFamily& fam = kv.second;
+    if (!fam.pending) continue;
+    FactorGroup& g = p.fgroups[kv.first];
+    int rc = launch_leaf_family(p, g, fam, st->wide[fam.wide_index], static_cast<float*>(p.arena),
+                                static_cast<const float*>(p.cpts), fam.pending_fresh, fam.pending_first, kLeafFull, s);
+    if (rc < 0) return rc;
+  }
+  return 0;
+}
+
+inline bool em_is_reduced(const Plan& p, size_t fi) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0) return false;
+  auto it = st->fused.find((int32_t)fi);
+  return it != st->fused.end() && it->second.em_ready;
+}
+
+// EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.
+inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0) return 0;
+  auto it = st->fused.find((int32_t)fi);
+  if (it == st->fused.end() || !it->second.em_ready) return 0;
+  FactorGroup& g = p.fgroups[fi];
+  const int64_t items = (int64_t)g.nodes.size() * g.cpt_elems;
+  hipLaunchKernelGGL(em_finalize_slots, dim3(wave_blocks(items)), dim3(256), 0, s, it->second.em_partial,
+                     static_cast<const float*>(p.cpts), g.d_cpt, (int32_t)g.nodes.size(), (int32_t)g.cpt_elems,
+                     it->second.slots, accum);
+  return launch_ok() ? 1 : -1;
+}
+
+
 template <typename T>
 int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t first_iteration,
-                       int32_t last_iteration, hipStream_t s) {
+                       int32_t last_iteration, int32_t reduce_last, hipStream_t s) {
   if constexpr (!std::is_same<T, float>::value) {
     return 0;
   } else {
@@ -393,30 +495,8 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       auto it = st->fused.find((int32_t)fi);
       if (it != st->fused.end()) {
         WideNode& w = st->wide[it->second.wide_index];
-        const int32_t vec = kLeafVec;
-        LeafFamilyFn fn = last_iteration ? leaf_family_lookup<true>(g.dims[0], g.dims[1])
-                                         : leaf_family_lookup<false>(g.dims[0], g.dims[1]);
-        if (!fn) return -1;
-        LeafFamilyArgs a;
-        a.f_in = g.d_in;
-        a.f_out = g.d_out;
-        a.cpt_off = g.d_cpt;
-        a.obs_off = it->second.d_obs_off;
-        a.c_off = it->second.d_c_off;
-        a.K = K;
-        a.chunks = w.chunks;
-        a.chunk_len = w.chunk_len;
-        a.part_mant = w.part_mant;
-        a.part_exp = w.part_exp;
-        a.scaled = w.scaled;
-        a.npad = p.npad;
-        a.ntiles = p.ntiles;
-        a.fresh = fresh;
-        a.prev_from_arrays = first_iteration;
-        hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / vec))), dim3(256), 0, s, arena, cpts, a);
-        if (!launch_ok()) return -1;
-        w.partials_valid = true;
-        return 1;
+        const int32_t mode = !last_iteration ? kLeafLoop : (reduce_last ? kLeafReduce : kLeafFull);
+        return launch_leaf_family(p, g, it->second, w, arena, cpts, fresh, first_iteration, mode, s);
       }
     }
     if (g.dims.size() == 1) {

@@ -327,10 +327,22 @@ struct LeafFamilyArgs {
   // first iteration of a bn_iterate call: the factor's previous message to the parent is read
   // from its array; later iterations rebuild it from the leaf's previous normaliser (see kernel)
   int32_t prev_from_arrays;
+  float* z_state;  // [K][npad] loop state: the leaf's normaliser z of the previous iteration
+  // kLeafReduce only
+  int64_t N;
+  float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable)
+  int32_t slots;      // ntiles * waves per tile
 };
-// Template flag FULL = last iteration of a bn_iterate call: write everything queries may read
-// (both variable -> factor messages, the message to the parent, c = log z); otherwise only the
-// loop state (message to the own variable, z).
+// Template parameter MODE
+//   kLeafLoop    inside a bn_iterate call: only the loop state is written (message to the own
+//                variable, z);
+//   kLeafFull    last iteration of a bn_iterate call: everything queries may read is written
+//                (both variable -> factor messages, the message to the parent, c = log z);
+//   kLeafReduce  last iteration of an EM step (bn_em_statistics): nothing of the message state is
+//                written; the iteration's values are used on the fly for c = log z and for the
+//                per-wave EM count sums.  The stored state stays one iteration behind, and the
+//                host re-runs this iteration in kLeafFull mode if anything asks for messages.
+constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 
 // 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
 // seed plus one Newton step.
@@ -395,6 +407,7 @@ struct LeafPtrs {  // wave-uniform
   float* v2f_par;
   float* v2f_own;
   float* c;
+  float* z;          // loop-state normaliser of this family
   const float* obs;  // nullptr = not observed
   const float* cpt;
 };
@@ -413,6 +426,7 @@ __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const f
   p.v2f_par = arena + a.f_in[2 * k];
   p.v2f_own = arena + a.f_in[2 * k + 1];
   p.c = arena + a.c_off[k];
+  p.z = a.z_state + (int64_t)k * a.npad;
   const int64_t obs = a.obs_off[k];
   p.obs = obs >= 0 ? arena + obs : nullptr;
   p.cpt = cpts + a.cpt_off[k];
@@ -428,13 +442,15 @@ __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const L
     st.prev_own[j] = a.fresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
     st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
   }
-  st.zp = (!a.fresh && !a.prev_from_arrays) ? loadv<V>(p.c, t, col) : splat<V>(1.f);
+  st.zp = (!a.fresh && !a.prev_from_arrays) ? loadv<V>(p.z, t, col) : splat<V>(1.f);
   return st;
 }
 
-template <int D0, int S, int V, bool FULL>
+template <int D0, int S, int V, int MODE>
 __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      LeafFamilyArgs a) {
+  constexpr bool FULL = MODE == kLeafFull;
+  constexpr bool REDUCE = MODE == kLeafReduce;
   constexpr int32_t kParts = 4 / V;
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -498,7 +514,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     const float* cpt = ptr.cpt;
 
     // Loop state per family between iterations: the factor's message to its own variable
-    // (f2v_own) and the leaf's normaliser z = sum_s ev[s] * f2v_own[s], kept in the c array.
+    // (f2v_own) and the leaf's normaliser z = sum_s ev[s] * f2v_own[s], kept in z_state.
     // The factor's previous message to the parent is cpt . (ev / z_prev): recomputed from
     // those 2+1 floats instead of stored and reloaded as D0 floats.
     fv<V> prev_par[D0];
@@ -541,7 +557,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         const float zf = (float)z[v];
-        if (FULL) {
+        if (FULL || REDUCE) {
           int de = 0;
           const double mz = frexp(z[v], &de);
           c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
         }
         z[v] = recip((double)zf);
       }
-      storev<V>(ptr.c, t, col, c);
+      storev<V>((FULL || REDUCE) ? ptr.c : ptr.z, t, col, c);
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         const float inv = (float)z[v];
@@ -586,6 +602,27 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, to_f_par[i]);
 #pragma unroll
       for (int32_t j = 0; j < S; ++j) storev<V>(ptr.v2f_own, t * S + j, col, to_f_own[j]);
+    }
+    if constexpr (REDUCE) {
+      // EM counts of this family over the wave's observations (padding masked), wave-reduced
+      float live[V];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) live[v] = (t * kTile + col + v < a.N) ? 1.f : 0.f;
+      float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) {
+          float x = 0.f;
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) x = fmaf(to_f_par[i].v[v] * live[v], to_f_own[j].v[v], x);
+#pragma unroll
+          for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+          if (lane == 0) dst[(int64_t)(i * S + j) * a.slots] = x;
+        }
+      ptr = ptr_next;
+      cur = nxt;
+      continue;
     }
     // factor contractions
     fv<V> new_par[D0], new_own[S];
@@ -628,6 +665,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     ptr = ptr_next;
     cur = nxt;
   }
+  if constexpr (REDUCE) return;
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
 #pragma unroll
@@ -649,6 +687,26 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       a.part_exp[row] = pe[s][0];
     }
   }
+}
+
+// accum[entry] = cpt[entry] * sum over the per-wave sums written by the kLeafReduce kernel.
+// One wave per CPT entry.   grid.x = ceil(entries / 4), block = 256
+__global__ void __launch_bounds__(256) em_finalize_slots(const float* __restrict__ em_partial,
+                                                        const float* __restrict__ cpts,
+                                                        const int64_t* __restrict__ cpt_off, int32_t K,
+                                                        int32_t entries_per_node, int32_t slots,
+                                                        double* __restrict__ accum) {
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (item >= (int64_t)K * entries_per_node) return;
+  const int32_t k = (int32_t)(item / entries_per_node);
+  const int32_t e = (int32_t)(item % entries_per_node);
+  const float* src = em_partial + item * slots;
+  double acc = 0.0;
+  for (int32_t sl = lane; sl < slots; sl += 64) acc += (double)src[sl];
+#pragma unroll
+  for (int32_t off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) accum[cpt_off[k] + e] = acc * (double)cpts[cpt_off[k] + e];
 }
 
 }  // namespace bn

@@ -343,6 +343,25 @@ class HipSpaInferenceMachine(IInferenceMachine):
             _native.check(self._lib.bn_em_accumulate(self._plan, ctypes.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def em_statistics(self):
+        """``(log_likelihood_tensor, expected_count_sums)`` of the entered evidence in one engine call.
+        When the iterations have not run yet (and no per-iteration callback is set) the last
+        iteration is evaluated on the fly for the statistics; message queries made afterwards
+        bring the stored messages up to date first, so results are the same either way."""
+        if not self.must_iterate or self._settings.callback:
+            return self.log_likelihood_tensor(), self.expected_count_sums()
+        ll = torch.empty((1,), device=self._device, dtype=torch.float64)
+        counts = torch.empty((self._lib.bn_plan_cpt_elements(self._plan),), device=self._device, dtype=torch.float64)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_em_statistics(self._plan, self._num_iterations,
+                                           1 if self._settings.average_log_likelihood else 0,
+                                           ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                           self._stream())
+            )
+        self.must_iterate = False
+        return ll, counts
+
     def split_counts(self, flat: torch.Tensor) -> List[torch.Tensor]:
         views, pos = [], 0
         for shape in self._cpt_shapes:

@@ -45,14 +45,22 @@ class EmBatchOptimizer(IBatchOptimizer):
                 machine = self._factory(self._network)
                 machine.enter_evidence(evidence)
                 deferred = cfg.deferred_logging and hasattr(machine, "log_likelihood_tensor")
-                ll = machine.log_likelihood_tensor() if deferred else machine.log_likelihood()
+                count_sums = None
+                if hasattr(machine, "em_statistics"):
+                    ll, count_sums = machine.em_statistics()
+                    if not deferred:
+                        ll = ll.item()
+                else:
+                    ll = machine.log_likelihood_tensor() if deferred else machine.log_likelihood()
                 if hasattr(machine, "expected_count_sums"):
                     # whole-network M-step on one flat buffer; nodes get views of it
                     if flat_model is None:
                         flat_model = FlatModel(self._network)
                     if flat is None or any(n.cpt._base is not flat for n in flat_model.nodes[:1]):
                         flat = flat_model.gather()
-                    sums, ll, _ = reduce_statistics(machine, machine.expected_count_sums(), ll, cfg.sharded)
+                    if count_sums is None:
+                        count_sums = machine.expected_count_sums()
+                    sums, ll, _ = reduce_statistics(machine, count_sums, ll, cfg.sharded)
                     flat = flat_model.m_step(sums, flat, cfg.learning_rate, cfg.regularization)
                     flat_model.assign(flat)
                 else:

@@ -33,11 +33,18 @@ class EmOptimizer(IOptimizer):
         for iteration in range(self._settings.num_iterations):
             machine = self._factory(self._network)
             machine.enter_evidence(evidence)
-            ll = machine.log_likelihood()
+            count_sums = None
+            if hasattr(machine, "em_statistics"):
+                ll, count_sums = machine.em_statistics()
+                ll = ll.item()
+            else:
+                ll = machine.log_likelihood()
             if hasattr(machine, "expected_count_sums"):
                 if flat_model is None:
                     flat_model = FlatModel(self._network)
-                sums, ll, _ = reduce_statistics(machine, machine.expected_count_sums(), ll, self._settings.sharded)
+                if count_sums is None:
+                    count_sums = machine.expected_count_sums()
+                sums, ll, _ = reduce_statistics(machine, count_sums, ll, self._settings.sharded)
                 flat_model.assign(flat_model.m_step(sums, None, None, None))
             else:
                 counts, ll = expected_counts(machine, self._network, self._settings.sharded, ll)

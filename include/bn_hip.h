@@ -152,6 +152,18 @@ int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream)
 int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream);
 
 /*
+ * One EM step's statistics in one call: num_iterations flooding iterations, then the
+ * log-likelihood (as bn_log_likelihood) and the expected-count sums (as bn_em_accumulate).
+ * Equivalent to bn_iterate + bn_log_likelihood + bn_em_accumulate, but the last iteration may
+ * be evaluated on the fly for the statistics without storing its messages; they are brought up
+ * to date automatically by the next call that reads or changes messages, evidence or CPTs.
+ * Replaces the body of EmBatchOptimizer.optimize's step up to the M-step
+ * (optimizers/em_batch_optimizer.py:44-48: enter_evidence excluded).
+ */
+int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
+                     void* stream);
+
+/*
  * Inspection: copy one message out as [N, S].
  *   owner      node whose factor is one end of the edge
  *   slot       -1 = edge to the owner's own variable, p >= 0 = edge to its p-th parent,

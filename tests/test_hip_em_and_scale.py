@@ -123,3 +123,46 @@ def test_full_batch_size_properties(name):
             # loopy iteration amplifies float32 rounding (the reference's own float32 run is off by 1.5e-4)
             rtol = 2e-4 if fx.meta["allow_loops"] else 4e-5
             np.testing.assert_allclose(sums.cpu().numpy(), fx[key], rtol=rtol, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["c3a_784_f32", "c3a_mini16_f32", "c2_docs2_f32", "c3b_784_f32"])
+def test_em_statistics_equals_separate_calls_and_leaves_queries_intact(name):
+    """bn_em_statistics may skip storing the last iteration's messages; its statistics must equal
+    bn_iterate + bn_log_likelihood + bn_em_accumulate, and every query made afterwards must give
+    what it gives after a plain bn_iterate (the engine completes the iteration on demand)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    ts = TorchSettings(device="cuda", dtype="float32")
+    network, observed, by_name = fx.build(ts)
+    settings = SpaInferenceMachineSettings(ts, True, num_iterations=fx.meta["num_iterations"],
+                                           allow_loops=fx.meta["allow_loops"])
+    ev = Evidence(fx.evidence_tensors("cuda"), ts)
+    plain = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
+    plain.enter_evidence(ev)
+    ll_plain = plain.log_likelihood_tensor()
+    counts_plain = plain.expected_count_sums()
+
+    fused = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
+    fused.enter_evidence(ev)
+    ll_fused, counts_fused = fused.em_statistics()
+    np.testing.assert_allclose(ll_fused.item(), ll_plain.item(), rtol=1e-7)
+    np.testing.assert_allclose(counts_fused.cpu().numpy(), counts_plain.cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+    nodes = list(network.nodes)
+    for a, b in zip(fused.infer_single_nodes(nodes), plain.infer_single_nodes(nodes)):
+        assert torch.equal(a, b)
+    probe = [nodes[0], nodes[-1]]
+    for a, b in zip(fused.infer_nodes_with_parents(probe), plain.infer_nodes_with_parents(probe)):
+        assert torch.equal(a, b)
+    for node in probe:
+        assert torch.equal(fused.local_log_likelihoods(node), plain.local_log_likelihoods(node))
+    # and the state keeps evolving identically: a second round of evidence on both
+    ev2 = Evidence([torch.flip(e, dims=[0]).contiguous() for e in fx.evidence_tensors("cuda")], ts)
+    plain.enter_evidence(ev2)
+    fused.enter_evidence(ev2)
+    l2, c2 = fused.em_statistics()
+    np.testing.assert_allclose(l2.item(), plain.log_likelihood_tensor().item(), rtol=1e-7)
+    np.testing.assert_allclose(c2.cpu().numpy(), plain.expected_count_sums().cpu().numpy(), rtol=2e-6, atol=1e-12)
