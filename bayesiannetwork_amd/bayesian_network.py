@@ -29,14 +29,61 @@ from .statistics import generate_random_probability_matrix, is_valid_probability
 from .torch_settings import TorchSettings
 
 
+class CptStore:
+    """The CPTs of all nodes of one network back to back in one flat tensor (network order).
+    Nodes attached to a store read their ``cpt`` as a view of ``flat``; replacing ``flat``
+    therefore re-parameterises the whole network in one assignment.  A node whose ``cpt`` is
+    assigned directly leaves the store (``attached`` drops below ``count``)."""
+
+    __slots__ = ("network", "flat", "count", "attached")
+
+    def __init__(self, network: "BayesianNetwork", flat: torch.Tensor):
+        self.network = network
+        self.flat = flat
+        self.count = 0
+        self.attached = 0
+
+    @property
+    def complete(self) -> bool:
+        return self.attached == self.count
+
+
 class Node:
     def __init__(self, cpt: torch.Tensor, name: Optional[str] = None):
         if not is_valid_probability_matrix(cpt):
             raise Exception("The CPT should sum to 1 along the last dimension.")
 
-        self.cpt = cpt
+        self._store: Optional[CptStore] = None
+        self._cpt = cpt
         self.num_states: int = int(cpt.shape[-1])
         self.name = name
+
+    @property
+    def cpt(self) -> torch.Tensor:
+        store = self._store
+        if store is None:
+            return self._cpt
+        flat = store.flat
+        if self._view_of is not flat:
+            self._view = flat[self._lo : self._hi].view(self._shape)
+            self._view_of = flat
+        return self._view
+
+    @cpt.setter
+    def cpt(self, value: torch.Tensor) -> None:
+        if self._store is not None:
+            self._store.attached -= 1
+            self._store = None
+            self._view = self._view_of = None
+        self._cpt = value
+
+    def attach(self, store: CptStore, lo: int, hi: int, shape) -> None:
+        """Read ``cpt`` from ``store.flat[lo:hi]`` (viewed as ``shape``) from now on."""
+        self.cpt = None  # leaves a previous store, if any
+        self._store, self._lo, self._hi, self._shape = store, lo, hi, tuple(shape)
+        self._view = self._view_of = None
+        store.count += 1
+        store.attached += 1
 
     @classmethod
     def random(cls, size, torch_settings: TorchSettings, name: Optional[str] = None) -> "Node":

@@ -32,6 +32,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels_fast.h"
 
 namespace bn {
@@ -344,6 +346,22 @@ struct LeafFamilyArgs {
 //                host re-runs this iteration in kLeafFull mode if anything asks for messages.
 constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 
+// Sum over the 64 lanes with data-parallel-primitive adds only (no LDS crossbar): quad swaps,
+// row (16-lane) mirrors, then the row broadcasts.  The total ends up in lane 63.
+__device__ __forceinline__ float wave_sum_lane63(float x) {
+  auto dpp = [](float v, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                decltype(row_mask)::value, 0xF, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
+  x += dpp(x, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror
+  x += dpp(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 -> rows 1,3
+  x += dpp(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 -> rows 2,3
+  return x;
+}
+
 // 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
 // seed plus one Newton step.
 __device__ __forceinline__ double recip(double x) {
@@ -616,9 +634,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
           float x = 0.f;
 #pragma unroll
           for (int32_t v = 0; v < V; ++v) x = fmaf(to_f_par[i].v[v] * live[v], to_f_own[j].v[v], x);
-#pragma unroll
-          for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-          if (lane == 0) dst[(int64_t)(i * S + j) * a.slots] = x;
+          x = wave_sum_lane63(x);
+          if (lane == 63) dst[(int64_t)(i * S + j) * a.slots] = x;
         }
       ptr = ptr_next;
       cur = nxt;

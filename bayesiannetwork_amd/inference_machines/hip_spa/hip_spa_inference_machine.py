@@ -206,7 +206,12 @@ class HipSpaInferenceMachine(IInferenceMachine):
                 raise ValueError("Networks containers loops; number of iterations must be set explicitly.")
             self._num_iterations = settings.num_iterations
 
-        self.set_cpts([node.cpt for node in self._nodes])
+        store = getattr(self._nodes[0], "_store", None) if self._nodes else None
+        if (store is not None and store.network is bayesian_network and store.complete
+                and store.count == len(self._nodes)):
+            self.set_cpts(store.flat)  # all CPTs already sit back to back in network order
+        else:
+            self.set_cpts([node.cpt for node in self._nodes])
         self.factor_graph = _FactorGraphView(bayesian_network)
         self.must_iterate: bool = True
         self._evidence_keepalive = None

@@ -38,7 +38,6 @@ class EmBatchOptimizer(IBatchOptimizer):
     def optimize(self, evidence_loader: EvidenceLoader) -> None:
         cfg = self._settings
         flat_model = None
-        flat = None
         for epoch in range(cfg.num_epochs):
             pending = []
             for iteration, evidence in enumerate(evidence_loader):
@@ -56,8 +55,7 @@ class EmBatchOptimizer(IBatchOptimizer):
                     # whole-network M-step on one flat buffer; nodes get views of it
                     if flat_model is None:
                         flat_model = FlatModel(self._network)
-                    if flat is None or any(n.cpt._base is not flat for n in flat_model.nodes[:1]):
-                        flat = flat_model.gather()
+                    flat = flat_model.gather()
                     if count_sums is None:
                         count_sums = machine.expected_count_sums()
                     sums, ll, _ = reduce_statistics(machine, count_sums, ll, cfg.sharded)

@@ -91,6 +91,8 @@ class FlatModel:
         self.num_rows = row_base
         self.row_ids = torch.cat(rows).to(self.device)
         self.inv_states = torch.cat(inv).to(self.device)
+        self._network = network
+        self._store = None
 
     def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
         out, pos = [], 0
@@ -100,7 +102,11 @@ class FlatModel:
         return out
 
     def gather(self) -> torch.Tensor:
-        """Current CPTs as one flat tensor in the model dtype."""
+        """Current CPTs as one flat tensor in the model dtype (the shared buffer itself when
+        every node still reads from it)."""
+        store = self._store
+        if store is not None and store.complete and store.flat.dtype == self.dtype:
+            return store.flat
         return torch.cat([n.cpt.detach().to(self.device, self.dtype).reshape(-1) for n in self.nodes])
 
     def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],
@@ -117,6 +123,22 @@ class FlatModel:
         return cpt.to(self.dtype)
 
     def assign(self, flat: torch.Tensor) -> None:
+        """Make ``flat`` the network's parameters.  Nodes that can read from a shared buffer
+        (this package's ``Node``) are switched in one assignment; others get a view each."""
+        store = self._store
+        if store is not None and store.complete:
+            store.flat = flat
+            return
+        if all(hasattr(n, "attach") for n in self.nodes):
+            from ..bayesian_network import CptStore
+
+            store = CptStore(self._network, flat)
+            pos = 0
+            for node, shape, size in zip(self.nodes, self.shapes, self.sizes):
+                node.attach(store, pos, pos + size, shape)
+                pos += size
+            self._store = store
+            return
         for node, view in zip(self.nodes, self.views(flat)):
             node.cpt = view
 
