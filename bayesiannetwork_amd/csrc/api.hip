@@ -159,6 +159,8 @@ void release(bn::Plan& p) {
   if (p.scratch) (void)hipFree(p.scratch);
   if (p.d_evidence_ptrs) (void)hipFree(p.d_evidence_ptrs);
   if (p.h_evidence_ptrs) (void)hipHostFree(p.h_evidence_ptrs);
+  for (void* e : p.staging_events)
+    if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   if (p.d_obs_off) (void)hipFree(p.d_obs_off);
   if (p.d_obs_states) (void)hipFree(p.d_obs_states);
   if (p.d_fill_off) (void)hipFree(p.d_fill_off);
@@ -194,8 +196,9 @@ template <typename T>
 int reset_messages_t(bn::Plan& p, hipStream_t s) {
   T* arena = static_cast<T*>(p.arena);
   p.obs_pending = p.fill_count > p.fill_messages;
-  const int64_t c_elems = (int64_t)p.n_nodes * p.npad;
-  BN_HIP_CHECK(hipMemsetAsync(arena + p.c_base, 0, c_elems * sizeof(T), s));
+  (void)arena;
+  (void)s;
+  p.c_stale = true;  // zeroed on demand: every iteration overwrites all of them anyway
   p.fresh = true;
   bn::invalidate_fast(p);
   return BN_OK;
@@ -205,6 +208,15 @@ int reset_messages_t(bn::Plan& p, hipStream_t s) {
 // reads or changes messages, evidence or CPTs.
 int complete_pending(bn::Plan& p, hipStream_t s) {
   if (bn::complete_pending_fast(p, s) < 0) return fail(BN_ERR_HIP, "launch of the leaf-family kernel failed");
+  return BN_OK;
+}
+
+// Normalisers read as zero between a reset and the first iteration.
+int settle_normalisers(bn::Plan& p, hipStream_t s) {
+  if (!p.c_stale) return BN_OK;
+  BN_HIP_CHECK(hipMemsetAsync(static_cast<char*>(p.arena) + (size_t)p.c_base * p.elem_size, 0,
+                              (size_t)p.n_nodes * p.npad * p.elem_size, s));
+  p.c_stale = false;
   return BN_OK;
 }
 
@@ -258,6 +270,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
       prof_end(s);
     }
     p.fresh = false;  // every variable -> factor message has been written; the factor pass writes the rest
+    p.c_stale = false;  // and every normaliser
     for (auto& g : p.fgroups) {
       const int32_t K = (int32_t)g.nodes.size();
       {
@@ -416,8 +429,15 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY(upload(p.obs_off, &p.d_obs_off, p.device_bytes));
     BN_TRY(upload(obs_states, &p.d_obs_states, p.device_bytes));
     BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_evidence_ptrs), p.observed.size() * sizeof(void*)));
-    BN_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&p.h_evidence_ptrs), p.observed.size() * sizeof(void*),
-                             hipHostMallocDefault));
+    BN_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&p.h_evidence_ptrs),
+                             bn::Plan::kStagingSlots * p.observed.size() * sizeof(void*), hipHostMallocDefault));
+    for (void*& e : p.staging_events) {
+      hipEvent_t ev;
+      BN_TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e = ev;
+    }
+    p.obs_all_pairs = p.dtype == BN_F32 && p.tile % 2 == 0;
+    for (int32_t st : obs_states) p.obs_all_pairs = p.obs_all_pairs && st == 2;
   }
   {
     // every message array and observation array starts uniform
@@ -504,10 +524,16 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
     if (!evidence_dev[i]) return fail(BN_ERR_INVALID, "an evidence pointer is null");
     max_states = std::max(max_states, p.states[p.observed[i]]);
   }
-  // the pinned staging table is reused by every call: wait until the previous copy has left it
-  BN_HIP_CHECK(hipStreamSynchronize(s));
-  std::memcpy(p.h_evidence_ptrs, evidence_dev, count * sizeof(void*));
-  BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, p.h_evidence_ptrs, count * sizeof(void*), hipMemcpyHostToDevice, s));
+  // next slot of the pinned staging ring; wait only if its previous upload is still in flight
+  const int32_t slot = p.staging_next;
+  p.staging_next = (slot + 1) % bn::Plan::kStagingSlots;
+  hipEvent_t slot_event = static_cast<hipEvent_t>(p.staging_events[slot]);
+  if (p.staging_used[slot]) BN_HIP_CHECK(hipEventSynchronize(slot_event));
+  void** staging = p.h_evidence_ptrs + (size_t)slot * count;
+  std::memcpy(staging, evidence_dev, count * sizeof(void*));
+  BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, staging, count * sizeof(void*), hipMemcpyHostToDevice, s));
+  BN_HIP_CHECK(hipEventRecord(slot_event, s));
+  p.staging_used[slot] = true;
   const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
   {
     double bytes = 0;
@@ -516,7 +542,11 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   }
   for (size_t first = 0; first < count; first += 65535) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
-    if (p.dtype == BN_F32) {
+    if (p.obs_all_pairs) {
+      hipLaunchKernelGGL(bn::evidence_scatter_pairs, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
+                         static_cast<float*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first),
+                         p.d_obs_off + first, p.N, p.tile, p.npad);
+    } else if (p.dtype == BN_F32) {
       hipLaunchKernelGGL(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
                          (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
                          p.d_obs_states + first, p.N, p.tile, p.ntiles);
@@ -547,6 +577,7 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = settle_normalisers(p, s)) return rc;
   const int64_t total = (int64_t)p.n_nodes * p.npad;
   const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
   prof_begin("log_likelihood", (double)p.n_nodes * (double)p.N * (double)p.elem_size, s);
@@ -583,6 +614,7 @@ int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* s
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
+  if (int rc = settle_normalisers(p, static_cast<hipStream_t>(stream))) return rc;
   return gather(p, p.c_off[node], -1, 1, out_dev, static_cast<hipStream_t>(stream));
 }
 

@@ -261,6 +261,35 @@ __global__ void __launch_bounds__(256) evidence_scatter(T* __restrict__ arena,
   arena[obs_off[o] + idx] = n < N ? src[n * S + s] : (T)1;
 }
 
+// Two-state float evidence, two observations per lane: 16 bytes in ([e0 e1 | e0 e1]), 8 bytes out
+// to each of the two state rows.  Sources that are not 16-byte aligned are read element-wise.
+// grid = (ceil(npad / 512), num_observed); tile must be even
+__global__ void __launch_bounds__(256) evidence_scatter_pairs(float* __restrict__ arena,
+                                                             const void* const* __restrict__ sources,
+                                                             const int64_t* __restrict__ obs_off, int64_t N,
+                                                             int32_t tile, int64_t npad) {
+  const int32_t o = blockIdx.y;
+  const int64_t n0 = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  if (n0 >= npad) return;
+  const float* src = static_cast<const float*>(sources[o]);
+  float4 x = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (n0 + 1 < N) {
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      x = *reinterpret_cast<const float4*>(src + 2 * n0);
+    } else {
+      x = make_float4(src[2 * n0], src[2 * n0 + 1], src[2 * n0 + 2], src[2 * n0 + 3]);
+    }
+  } else if (n0 < N) {
+    x.x = src[2 * n0];
+    x.y = src[2 * n0 + 1];
+  }
+  const int64_t t = n0 / tile;
+  const int32_t lt = (int32_t)(n0 % tile);
+  float* dst = arena + obs_off[o] + t * 2 * tile + lt;
+  *reinterpret_cast<float2*>(dst) = make_float2(x.x, x.z);
+  *reinterpret_cast<float2*>(dst + tile) = make_float2(x.y, x.w);
+}
+
 // fill one region with a constant.  grid.x = ceil(count/256)
 template <typename T>
 __global__ void __launch_bounds__(256) fill_region(T* __restrict__ dst, int64_t count, T value) {

@@ -15,18 +15,19 @@
 // whose own variable has no children — one kernel does the whole iteration for them:
 //
 //   leaf_family_p1 one wave per (chunk of families, tile); per family k it
-//                    reads  the factor's previous messages f2v_{k->parent}, f2v_{k->own} and the
-//                           own variable's observation,
-//                    forms  the parent's message to the factor from P' (the wide emission) and
-//                           the own variable's message to the factor and normaliser c (its
-//                           whole variable pass: inputs are just observation x previous message),
+//                    reads  the own variable's observation ev and the leaf's normaliser
+//                           z = sum_s ev[s] * (factor's previous message to the leaf)[s],
+//                    forms  the parent's message to the factor from P' (the wide emission; the
+//                           factor's previous message to the parent is cpt . ev / z_prev and the
+//                           emission is normalised, so q = cpt . ev is all it needs) and the own
+//                           variable's message ev / z with c = log z (its whole variable pass),
 //                    runs   both contractions with the CPT,
-//                    writes the new f2v messages over the old ones, and
+//                    writes the leaf's next z, and
 //                    folds  the new message to the parent into the chunk's partial product for
 //                           the next iteration's wide_combine.
-//   The variable -> factor messages never touch HBM inside the loop; they are stored only in
-//   the last iteration of a bn_iterate call, for marginal / EM queries.
-//   Per observation and iteration this moves D0+2S floats in and D0+S+1 out per family (27
+//   No message touches HBM inside the loop; all four are stored only in the last iteration of
+//   a bn_iterate call, for marginal / EM queries, and read back by the first iteration of the
+//   next call.  Per observation and iteration this moves S+1 floats in and 1 out per family (4
 //   floats for the 784-leaf model's (10,2) families) instead of the 61 of the unfused passes.
 #pragma once
 
@@ -329,15 +330,14 @@ struct LeafFamilyArgs {
   // first iteration of a bn_iterate call: the factor's previous message to the parent is read
   // from its array; later iterations rebuild it from the leaf's previous normaliser (see kernel)
   int32_t prev_from_arrays;
-  float* z_state;  // [K][npad] loop state: the leaf's normaliser z of the previous iteration
+  float* z_state;  // [K][npad] loop state: the leaf's normaliser z for the coming iteration
   // kLeafReduce only
   int64_t N;
   float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable)
   int32_t slots;      // ntiles * waves per tile
 };
 // Template parameter MODE
-//   kLeafLoop    inside a bn_iterate call: only the loop state is written (message to the own
-//                variable, z);
+//   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
 //   kLeafFull    last iteration of a bn_iterate call: everything queries may read is written
 //                (both variable -> factor messages, the message to the parent, c = log z);
 //   kLeafReduce  last iteration of an EM step (bn_em_statistics): nothing of the message state is
@@ -432,8 +432,8 @@ struct LeafPtrs {  // wave-uniform
 
 template <int S, int V>
 struct LeafState {
-  fv<V> prev_own[S], ev[S];
-  fv<V> zp;  // previous normaliser
+  fv<V> ev[S];
+  fv<V> z;  // the leaf's normaliser for this iteration: sum_s ev[s] * (previous message from the factor)[s]
 };
 
 __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const float* __restrict__ cpts,
@@ -451,16 +451,35 @@ __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const f
   return p;
 }
 
+// z of one leaf from its evidence and the factor's previous message, rounded to float
+template <int S, int V>
+__device__ __forceinline__ fv<V> leaf_normaliser(const fv<V>* ev, const fv<V>* from_factor) {
+  fv<V> z;
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) {
+    double acc = 0.0;
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) acc = fma((double)ev[j].v[v], (double)from_factor[j].v[v], acc);
+    z.v[v] = (float)acc;
+  }
+  return z;
+}
+
 template <int S, int V>
 __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const LeafFamilyArgs& a, int64_t t,
                                                       int32_t col) {
   LeafState<S, V> st;
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) {
-    st.prev_own[j] = a.fresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
-    st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
+  for (int32_t j = 0; j < S; ++j) st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
+  if (a.fresh || a.prev_from_arrays) {
+    fv<V> own[S];
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j)
+      own[j] = a.fresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
+    st.z = leaf_normaliser<S, V>(st.ev, own);
+  } else {
+    st.z = loadv<V>(p.z, t, col);
   }
-  st.zp = (!a.fresh && !a.prev_from_arrays) ? loadv<V>(p.z, t, col) : splat<V>(1.f);
   return st;
 }
 
@@ -492,9 +511,10 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   const int32_t first = chunk * a.chunk_len;
   const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
   if (first >= last) return;
-  // the parent's scaled product for this lane's observations, as float mantissa + exponent
-  float pf_m[D0][V];
-  int32_t pf_e[D0][V];
+  // The parent's scaled product P' (largest state = 1) for this lane's observations, in float.
+  // A state whose share is below float range reads as zero: its message to a leaf factor would
+  // be below 2^-100 of the leading state's and cannot change any sum it enters.
+  float pf[D0][V];
   {
     const double* scaled = a.scaled + t * kTile + col;
 #pragma unroll
@@ -515,11 +535,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
         pv[0] = scaled[(int64_t)i * a.npad];
       }
 #pragma unroll
-      for (int32_t v = 0; v < V; ++v) {
-        int de = 0;
-        pf_m[i][v] = (float)frexp(pv[v], &de);
-        pf_e[i][v] = de < -4000 ? -4000 : de;
-      }
+      for (int32_t v = 0; v < V; ++v) pf[i][v] = (float)pv[v];
     }
   }
 
@@ -531,139 +547,121 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     const LeafState<S, V> nxt = leaf_state<S, V>(ptr_next, a, t, col);
     const float* cpt = ptr.cpt;
 
-    // Loop state per family between iterations: the factor's message to its own variable
-    // (f2v_own) and the leaf's normaliser z = sum_s ev[s] * f2v_own[s], kept in z_state.
-    // The factor's previous message to the parent is cpt . (ev / z_prev): recomputed from
-    // those 2+1 floats instead of stored and reloaded as D0 floats.
-    fv<V> prev_par[D0];
-    if (a.fresh) {
+    // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the
+    // parent is q / z; and because the parent's message back is normalised over its states, q
+    // also stands in for the factor's previous message to the parent (q / z_prev) in the quotient.
+    fv<V> q[D0];
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i) prev_par[i] = splat<V>(1.0f / (float)D0);
-    } else if (a.prev_from_arrays) {
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i) prev_par[i] = loadv<V>(ptr.f2v_par, t * D0 + i, col);
-    } else {
-      fv<V> tfo[S];
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) {
-        const float inv = (float)recip((double)cur.zp.v[v]);
-#pragma unroll
-        for (int32_t j = 0; j < S; ++j) tfo[j].v[v] = cur.ev[j].v[v] * inv;
-      }
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i) {
-        prev_par[i] = splat<V>(0.f);
-#pragma unroll
-        for (int32_t j = 0; j < S; ++j)
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v) prev_par[i].v[v] = fmaf(cpt[i * S + j], tfo[j].v[v], prev_par[i].v[v]);
-      }
-    }
-
-    // own (leaf) variable: P = ev * prev_own, z = sum P, c = log z, message to the factor = ev / z
-    // (with z rounded to float first, so that the next iteration can rebuild the same message)
-    fv<V> to_f_own[S];
-    {
-      double z[V];
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) z[v] = 0.0;
+    for (int32_t i = 0; i < D0; ++i) {
+      q[i] = splat<V>(0.f);
 #pragma unroll
       for (int32_t j = 0; j < S; ++j)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) z[v] = fma((double)cur.ev[j].v[v], (double)cur.prev_own[j].v[v], z[v]);
+        for (int32_t v = 0; v < V; ++v) q[i].v[v] = fmaf(cpt[i * S + j], cur.ev[j].v[v], q[i].v[v]);
+    }
+    // parent's message to this factor, before normalisation: r = P' / (previous message to the parent)
+    fv<V> r[D0];
+    float inv_sum[V];
+    {
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) inv_sum[v] = 0.f;
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        fv<V> prev;
+        if (a.fresh) {
+          prev = splat<V>(1.0f / (float)D0);
+        } else if (a.prev_from_arrays) {
+          prev = loadv<V>(ptr.f2v_par, t * D0 + i, col);
+        } else {
+          prev = q[i];
+        }
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          r[i].v[v] = pf[i][v] * __builtin_amdgcn_rcpf(prev.v[v]);
+          inv_sum[v] += r[i].v[v];
+        }
+      }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) inv_sum[v] = __builtin_amdgcn_rcpf(inv_sum[v]);
+    }
+    // own (leaf) variable: c = log z, message to the factor = ev / z
+    float inv_z[V];
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) inv_z[v] = (float)recip((double)cur.z.v[v]);
+    if (FULL || REDUCE) {
       fv<V> c;
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
-        const float zf = (float)z[v];
-        if (FULL || REDUCE) {
-          int de = 0;
-          const double mz = frexp(z[v], &de);
-          c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf((float)mz));
-        } else {
-          c.v[v] = zf;
-        }
-        z[v] = recip((double)zf);
+        int de = 0;
+        const float mz = frexpf(cur.z.v[v], &de);
+        c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
       }
-      storev<V>((FULL || REDUCE) ? ptr.c : ptr.z, t, col, c);
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) {
-        const float inv = (float)z[v];
-#pragma unroll
-        for (int32_t j = 0; j < S; ++j) to_f_own[j].v[v] = cur.ev[j].v[v] * inv;
-      }
+      storev<V>(ptr.c, t, col, c);
     }
-    // wide parent: message to this factor = (P'/prev_par) normalised, in float: this message
-    // only reaches the leaf, its rounding never enters the wide product.  P' is held as a float
-    // mantissa and an exponent (<= 0, relative to the largest state), applied with ldexp after
-    // the division, so a state only vanishes when its quotient itself is below float range.
-    fv<V> to_f_par[D0];
-    {
-      float sum[V];
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) sum[v] = 0.f;
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          to_f_par[i].v[v] = ldexpf(pf_m[i][v] * __builtin_amdgcn_rcpf(prev_par[i].v[v]), pf_e[i][v]);
-          sum[v] += to_f_par[i].v[v];
-        }
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) sum[v] = __builtin_amdgcn_rcpf(sum[v]);
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) to_f_par[i].v[v] *= sum[v];
-    }
-    if (FULL) {
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, to_f_par[i]);
-#pragma unroll
-      for (int32_t j = 0; j < S; ++j) storev<V>(ptr.v2f_own, t * S + j, col, to_f_own[j]);
-    }
-    if constexpr (REDUCE) {
-      // EM counts of this family over the wave's observations (padding masked), wave-reduced
-      float live[V];
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) live[v] = (t * kTile + col + v < a.N) ? 1.f : 0.f;
-      float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-        for (int32_t j = 0; j < S; ++j) {
-          float x = 0.f;
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v) x = fmaf(to_f_par[i].v[v] * live[v], to_f_own[j].v[v], x);
-          x = wave_sum_lane63(x);
-          if (lane == 63) dst[(int64_t)(i * S + j) * a.slots] = x;
-        }
-      ptr = ptr_next;
-      cur = nxt;
-      continue;
-    }
-    // factor contractions
     fv<V> new_par[D0], new_own[S];
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) new_par[i] = splat<V>(0.f);
+    for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) new_par[i].v[v] = q[i].v[v] * inv_z[v];
+    if constexpr (FULL || REDUCE) {
+      fv<V> to_f_own[S];
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = cur.ev[j].v[v] * inv_z[v];
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) r[i].v[v] *= inv_sum[v];  // now the normalised message
+      if constexpr (REDUCE) {
+        // EM counts of this family over the wave's observations (padding masked), wave-reduced
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v)
+            if (t * kTile + col + v >= a.N) to_f_own[j].v[v] = 0.f;
+        float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
+#pragma unroll
+        for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+          for (int32_t j = 0; j < S; ++j) {
+            float x = 0.f;
+#pragma unroll
+            for (int32_t v = 0; v < V; ++v) x = fmaf(r[i].v[v], to_f_own[j].v[v], x);
+            x = wave_sum_lane63(x);
+            if (lane == 63) dst[(int64_t)(i * S + j) * a.slots] = x;
+          }
+        ptr = ptr_next;
+        cur = nxt;
+        continue;
+      }
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, r[i]);
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) storev<V>(ptr.v2f_own, t * S + j, col, to_f_own[j]);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.f2v_par, t * D0 + i, col, new_par[i]);
+    }
+    // factor's message to the leaf: cpt^T . (normalised message from the parent)
 #pragma unroll
     for (int32_t j = 0; j < S; ++j) new_own[j] = splat<V>(0.f);
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j) {
-        const float cv = cpt[i * S + j];
+      for (int32_t j = 0; j < S; ++j)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          new_par[i].v[v] = fmaf(cv, to_f_own[j].v[v], new_par[i].v[v]);
-          new_own[j].v[v] = fmaf(cv, to_f_par[i].v[v], new_own[j].v[v]);
-        }
-      }
+        for (int32_t v = 0; v < V; ++v) new_own[j].v[v] = fmaf(cpt[i * S + j], r[i].v[v], new_own[j].v[v]);
     if (FULL) {
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.f2v_par, t * D0 + i, col, new_par[i]);
-    }
+      for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
+    } else {
+      // r was left un-normalised in loop mode: one scale of the S sums instead of D0 messages
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
+      for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) new_own[j].v[v] *= inv_sum[v];
+      storev<V>(ptr.z, t, col, leaf_normaliser<S, V>(cur.ev, new_own));
+    }
     // fold into the partial product for the parent's next combine
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i)

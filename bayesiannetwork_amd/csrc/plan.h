@@ -95,7 +95,16 @@ struct Plan {
   double* scratch = nullptr;   // reduction partials
   int64_t scratch_elems = 0;
   void** d_evidence_ptrs = nullptr;  // device array of evidence source addresses
-  void** h_evidence_ptrs = nullptr;  // pinned staging for the above
+  // pinned staging for the above: a ring of kStagingSlots tables, each guarded by an event that
+  // marks when its last upload has left it, so that bn_enter_evidence never waits for the device
+  // unless the host runs kStagingSlots calls ahead
+  static constexpr int32_t kStagingSlots = 8;
+  void** h_evidence_ptrs = nullptr;
+  void* staging_events[kStagingSlots] = {};  // hipEvent_t
+  bool staging_used[kStagingSlots] = {};
+  int32_t staging_next = 0;
+  bool obs_all_pairs = false;  // float plan whose observed nodes all have two states
+  bool c_stale = false;        // normalisers are to read as zero (reset since the last iteration)
   int64_t* d_obs_off = nullptr;
   int32_t* d_obs_states = nullptr;
   int64_t* d_fill_off = nullptr;    // every message / observation array, for the uniform reset
