@@ -577,6 +577,7 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_normalisers(p, s)) return rc;
   const int64_t total = (int64_t)p.n_nodes * p.npad;
   const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
@@ -614,6 +615,7 @@ int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* s
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
+  if (int rc = complete_pending(p, static_cast<hipStream_t>(stream))) return rc;
   if (int rc = settle_normalisers(p, static_cast<hipStream_t>(stream))) return rc;
   return gather(p, p.c_off[node], -1, 1, out_dev, static_cast<hipStream_t>(stream));
 }
@@ -691,7 +693,21 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   if (int rc = settle_observations(p, s)) return rc;
   int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 1, s) : iterate_t<double>(p, num_iterations, 1, s);
   if (rc != BN_OK) return rc;
-  rc = bn_log_likelihood(plan, average, ll_out_dev, stream);
+  {
+    // the fused families left their normalisers as per-observation partial sums
+    const int used = bn::ll_partials_reduced(p, p.scratch, kLlBlocks, s);
+    if (used < 0) return fail(BN_ERR_HIP, "launch of ll_partial_listed failed");
+    if (used > 0) {
+      prof_begin("log_likelihood", (double)p.N * 8.0, s);
+      hipLaunchKernelGGL(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, used, average ? 1.0 / (double)p.N : 1.0,
+                         ll_out_dev);
+      BN_LAUNCH_CHECK("sum_partials");
+      prof_end(s);
+      rc = BN_OK;
+    } else {
+      rc = bn_log_likelihood(plan, average, ll_out_dev, stream);
+    }
+  }
   if (rc != BN_OK) return rc;
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
 }

@@ -46,6 +46,8 @@ struct FusedFamily {
   float* z_state = nullptr;     // [K][npad] loop-state normalisers
   float* em_partial = nullptr;  // [K][entries][slots], written by the reduce-mode kernel
   int32_t slots = 0;
+  double* ll_part = nullptr;    // [chunks][npad], written by the reduce-mode kernel
+  int32_t ll_rows = 0;
   // the last iteration ran in reduce mode: stored messages are one iteration behind until
   // complete_pending_fast re-runs it in full mode with these flags
   bool pending = false;
@@ -54,6 +56,10 @@ struct FusedFamily {
 };
 
 struct FastState {
+  // normaliser arrays of the nodes no fused family serves (the rest of a log-likelihood sum
+  // comes from the families' ll_part rows when their last iteration ran in reduce mode)
+  int64_t* d_ll_offs = nullptr;
+  int64_t n_ll_offs = 0;
   std::vector<WideNode> wide;
   std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
   std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
@@ -111,7 +117,9 @@ inline void release_fast(Plan& p) {
     if (kv.second.d_c_off) (void)hipFree(kv.second.d_c_off);
     if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
     if (kv.second.z_state) (void)hipFree(kv.second.z_state);
+    if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
   }
+  if (st->d_ll_offs) (void)hipFree(st->d_ll_offs);
   fast_states().erase(&p);
 }
 
@@ -194,6 +202,13 @@ inline int prepare_fast(Plan& p) {
     for (int32_t j : p.vgroups[gi].nodes) all = all && handled[j];
     st.vgroup_skip[gi] = all ? 1 : 0;
   }
+  {
+    std::vector<int64_t> offs;
+    for (int32_t j = 0; j < p.n_nodes; ++j)
+      if (!handled[j]) offs.push_back(p.c_off[j]);
+    st.n_ll_offs = (int64_t)offs.size();
+    if (!dev_upload(offs, &st.d_ll_offs, p.device_bytes)) return -2;
+  }
   // chunk geometry + scratch
   for (auto& w : st.wide) {
     if (w.fused_fgroup < 0) {
@@ -215,6 +230,13 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), rows * sizeof(int32_t)) != hipSuccess) return -2;
     if (hipMalloc(reinterpret_cast<void**>(&w.scaled), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
     p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 8);
+    if (w.fused_fgroup >= 0) {
+      FusedFamily& fam = st.fused[w.fused_fgroup];
+      fam.ll_rows = w.chunks;
+      if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)w.chunks * p.npad * sizeof(double)) != hipSuccess)
+        return -2;
+      p.device_bytes += (int64_t)((size_t)w.chunks * p.npad * sizeof(double));
+    }
   }
   fast_states()[&p] = std::move(st);
   return 0;
@@ -426,6 +448,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.z_state = fam.z_state;
   a.em_partial = fam.em_partial;
   a.slots = fam.slots;
+  a.ll_part = fam.ll_part;
   hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
@@ -462,6 +485,31 @@ inline bool em_is_reduced(const Plan& p, size_t fi) {
   if (!st || p.dtype != 0) return false;
   auto it = st->fused.find((int32_t)fi);
   return it != st->fused.end() && it->second.em_ready;
+}
+
+// Log-likelihood partial sums when every fused family's last iteration ran in reduce mode (their
+// normalisers exist only as ll_part rows).  Returns the number of partials written, 0 if the
+// plan is not in that state, -1 on a launch failure.
+inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hipStream_t s) {
+  FastState* st = fast_state(p);
+  if (!st || p.dtype != 0 || st->fused.empty()) return 0;
+  for (auto& kv : st->fused)
+    if (!kv.second.pending) return 0;
+  int32_t used = 0;
+  bool listed_done = false;
+  for (auto& kv : st->fused) {
+    const FusedFamily& fam = kv.second;
+    const int64_t n_listed = listed_done ? 0 : st->n_ll_offs;
+    const int64_t rows = n_listed + fam.ll_rows;
+    const int32_t blocks = (int32_t)std::min<int64_t>(max_blocks - used, rows * ((p.npad + 255) / 256));
+    if (blocks <= 0) return -1;
+    hipLaunchKernelGGL(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+                       st->d_ll_offs, n_listed, fam.ll_part, (int64_t)fam.ll_rows, p.N, p.npad, partial + used);
+    if (!launch_ok()) return -1;
+    used += blocks;
+    listed_done = true;
+  }
+  return used;
 }
 
 // EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.

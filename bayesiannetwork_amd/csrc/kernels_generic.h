@@ -381,6 +381,33 @@ __global__ void __launch_bounds__(256) ll_partial(const T* __restrict__ c, int64
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// Same sum when part of it already exists as per-observation partial sums: adds the normalisers
+// of the listed arrays (offsets into the arena, npad elements each) and `extra_rows` rows of
+// npad doubles.  grid.x = number of partials written
+template <typename T>
+__global__ void __launch_bounds__(256) ll_partial_listed(const T* __restrict__ arena,
+                                                        const int64_t* __restrict__ c_offs, int64_t n_listed,
+                                                        const double* __restrict__ extra, int64_t extra_rows,
+                                                        int64_t N, int64_t npad, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  const int64_t per_row = ((npad + 255) / 256) * 256;  // a row never shares a thread stride with the next
+  const int64_t total = (n_listed + extra_rows) * per_row;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / per_row;
+    const int64_t n = idx - row * per_row;
+    if (n >= N) continue;
+    acc += row < n_listed ? (double)arena[c_offs[row] + n] : extra[(row - n_listed) * npad + n];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) red[threadIdx.x] += red[threadIdx.x + step];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 __global__ void __launch_bounds__(256) sum_partials(const double* __restrict__ partial, int32_t count,
                                                    double scale, double* __restrict__ out) {
   __shared__ double red[256];

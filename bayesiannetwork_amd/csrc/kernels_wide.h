@@ -335,14 +335,15 @@ struct LeafFamilyArgs {
   int64_t N;
   float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable)
   int32_t slots;      // ntiles * waves per tile
+  double* ll_part;    // [chunks][npad] sum over the chunk's families of c = log z, per observation
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
 //   kLeafFull    last iteration of a bn_iterate call: everything queries may read is written
 //                (both variable -> factor messages, the message to the parent, c = log z);
 //   kLeafReduce  last iteration of an EM step (bn_em_statistics): nothing of the message state is
-//                written; the iteration's values are used on the fly for c = log z and for the
-//                per-wave EM count sums.  The stored state stays one iteration behind, and the
+//                written; the iteration's values are used on the fly for the per-observation sums
+//                of c = log z over each chunk's families and for the per-wave EM count sums.  The stored state stays one iteration behind, and the
 //                host re-runs this iteration in kLeafFull mode if anything asks for messages.
 constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 
@@ -539,6 +540,9 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     }
   }
 
+  double ll_acc[V];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) ll_acc[v] = 0.0;
   LeafPtrs ptr = leaf_ptrs(arena, cpts, a, first);
   LeafState<S, V> cur = leaf_state<S, V>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
@@ -595,8 +599,9 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
         int de = 0;
         const float mz = frexpf(cur.z.v[v], &de);
         c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
+        if (REDUCE) ll_acc[v] += (double)c.v[v];
       }
-      storev<V>(ptr.c, t, col, c);
+      if (FULL) storev<V>(ptr.c, t, col, c);
     }
     fv<V> new_par[D0], new_own[S];
 #pragma unroll
@@ -680,7 +685,12 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     ptr = ptr_next;
     cur = nxt;
   }
-  if constexpr (REDUCE) return;
+  if constexpr (REDUCE) {
+    double* dst = a.ll_part + (int64_t)chunk * a.npad + t * kTile + col;
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) dst[v] = ll_acc[v];
+    return;
+  }
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
 #pragma unroll
