@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dispatch_fast.h"
+#include "launch.h"
 #include "kernels_generic.h"
 #include "plan.h"
 
@@ -72,16 +73,19 @@ bn::FactorDims make_dims(const std::vector<int32_t>& dims) {
 
 constexpr int64_t kLdsLimit = 158 * 1024;
 
+// Timing regions: one record per prof_begin/prof_end bracket, holding the event pair of every
+// kernel launched inside it (see launch.h).
 struct ProfRecord {
   std::string label;
   double alg_bytes;
-  hipEvent_t start, stop;
+  std::vector<hipEvent_t> events;  // start, stop, start, stop, ...
 };
 std::mutex g_prof_mutex;
 std::vector<ProfRecord> g_prof;
 std::atomic<bool> g_profiling{false};
+bool g_region_open = false;
 
-std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than recording it
+std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than using it
 
 bool take_event(hipEvent_t* ev) {
   if (!g_event_pool.empty()) {
@@ -92,25 +96,32 @@ bool take_event(hipEvent_t* ev) {
   return hipEventCreate(ev) == hipSuccess;
 }
 
-void prof_begin(const std::string& label, double alg_bytes, hipStream_t s) {
+bool next_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  if (!g_region_open || g_prof.empty()) return false;
+  if (!take_event(start)) return false;
+  if (!take_event(stop)) {
+    g_event_pool.push_back(*start);
+    return false;
+  }
+  g_prof.back().events.push_back(*start);
+  g_prof.back().events.push_back(*stop);
+  return true;
+}
+
+void prof_begin(const std::string& label, double alg_bytes, hipStream_t) {
   if (!g_profiling.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
   ProfRecord r;
   r.label = label;
   r.alg_bytes = alg_bytes;
-  if (!take_event(&r.start)) return;
-  if (!take_event(&r.stop)) {
-    g_event_pool.push_back(r.start);
-    return;
-  }
-  (void)hipEventRecord(r.start, s);
   g_prof.push_back(std::move(r));
+  g_region_open = true;
 }
 
-void prof_end(hipStream_t s) {
-  if (!g_profiling.load(std::memory_order_relaxed)) return;
+void prof_end(hipStream_t) {
   std::lock_guard<std::mutex> lock(g_prof_mutex);
-  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().stop, s);
+  g_region_open = false;
 }
 
 // Compulsory bytes of one launch (see bn_profile_report in bn_hip.h).
@@ -183,7 +194,7 @@ int fill_arrays(bn::Plan& p, int64_t first_array, int64_t count, hipStream_t s) 
   const int32_t gx = (int32_t)std::min<int64_t>((max_elems + 255) / 256, 4096);
   for (int64_t first = 0; first < count; first += 65535) {
     const int32_t cnt = (int32_t)std::min<int64_t>(count - first, 65535);
-    hipLaunchKernelGGL(bn::fill_uniform<T>, dim3(gx, cnt), dim3(256), 0, s, arena,
+    bn::launch(bn::fill_uniform<T>, dim3(gx, cnt), dim3(256), 0, s, arena,
                        p.d_fill_off + first_array + first, p.d_fill_states + first_array + first, p.npad);
     BN_LAUNCH_CHECK("fill_uniform");
   }
@@ -263,7 +274,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         if (lds > 48 * 1024)
           BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::variable_pass_generic<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bn::variable_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, g.d_in,
+        bn::launch(bn::variable_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, g.d_in,
                            g.d_out, g.d_c, K, g.num_inputs, g.num_states, p.tile, p.ntiles, fresh);
         BN_LAUNCH_CHECK("variable_pass_generic");
       }
@@ -288,7 +299,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         if (lds > 48 * 1024)
           BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::factor_pass_generic<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bn::factor_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, cpts,
+        bn::launch(bn::factor_pass_generic<T>, dim3((uint32_t)blocks), dim3(64), lds, s, arena, cpts,
                            g.d_in, g.d_out, g.d_cpt, K, fd, p.tile, p.ntiles);
         BN_LAUNCH_CHECK("factor_pass_generic");
       }
@@ -326,7 +337,7 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
     const uint32_t gx = (uint32_t)((fd.elems + 255) / 256);
     for (int32_t first = 0; first < K; first += 65535) {
       const int32_t cnt = std::min(K - first, 65535);
-      hipLaunchKernelGGL(bn::em_partial_generic<T>, dim3(gx, nchunks, cnt), dim3(256), lds, s, arena,
+      bn::launch(bn::em_partial_generic<T>, dim3(gx, nchunks, cnt), dim3(256), lds, s, arena,
                          g.d_in + (int64_t)first * fd.arity, fd, p.N, p.tile, p.ntiles, nchunks, partial,
                          g.d_cpt + first);
       BN_LAUNCH_CHECK("em_partial_generic");
@@ -334,7 +345,7 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
     prof_end(s);
   }
   prof_begin("em_finalize", 0.0, s);
-  hipLaunchKernelGGL(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
+  bn::launch(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
                      cpts, p.cpt_total, nchunks, accum);
   BN_LAUNCH_CHECK("em_finalize");
   prof_end(s);
@@ -543,15 +554,15 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   for (size_t first = 0; first < count; first += 65535) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
     if (p.obs_all_pairs) {
-      hipLaunchKernelGGL(bn::evidence_scatter_pairs, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
+      bn::launch(bn::evidence_scatter_pairs, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
                          static_cast<float*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first),
                          p.d_obs_off + first, p.N, p.tile, p.npad);
     } else if (p.dtype == BN_F32) {
-      hipLaunchKernelGGL(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
+      bn::launch(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
                          (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
                          p.d_obs_states + first, p.N, p.tile, p.ntiles);
     } else {
-      hipLaunchKernelGGL(bn::evidence_scatter<double>, dim3(gx, cnt), dim3(256), 0, s,
+      bn::launch(bn::evidence_scatter<double>, dim3(gx, cnt), dim3(256), 0, s,
                          static_cast<double*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first),
                          p.d_obs_off + first, p.d_obs_states + first, p.N, p.tile, p.ntiles);
     }
@@ -583,15 +594,15 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
   prof_begin("log_likelihood", (double)p.n_nodes * (double)p.N * (double)p.elem_size, s);
   if (p.dtype == BN_F32) {
-    hipLaunchKernelGGL(bn::ll_partial<float>, dim3(blocks), dim3(256), 0, s,
+    bn::launch(bn::ll_partial<float>, dim3(blocks), dim3(256), 0, s,
                        static_cast<const float*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
   } else {
-    hipLaunchKernelGGL(bn::ll_partial<double>, dim3(blocks), dim3(256), 0, s,
+    bn::launch(bn::ll_partial<double>, dim3(blocks), dim3(256), 0, s,
                        static_cast<const double*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
   }
   BN_LAUNCH_CHECK("ll_partial");
   const double scale = average ? 1.0 / (double)p.N : 1.0;
-  hipLaunchKernelGGL(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, scale, out_dev);
+  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, scale, out_dev);
   BN_LAUNCH_CHECK("sum_partials");
   prof_end(s);
   return BN_OK;
@@ -601,10 +612,10 @@ static int gather(bn::Plan& p, int64_t a_off, int64_t b_off, int32_t states, voi
   const int64_t total = p.N * states;
   const uint32_t blocks = (uint32_t)((total + 255) / 256);
   if (p.dtype == BN_F32) {
-    hipLaunchKernelGGL(bn::gather_rows<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+    bn::launch(bn::gather_rows<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
                        a_off, b_off, static_cast<float*>(out_dev), p.N, states, p.tile);
   } else {
-    hipLaunchKernelGGL(bn::gather_rows<double>, dim3(blocks), dim3(256), 0, s, static_cast<const double*>(p.arena),
+    bn::launch(bn::gather_rows<double>, dim3(blocks), dim3(256), 0, s, static_cast<const double*>(p.arena),
                        a_off, b_off, static_cast<double*>(out_dev), p.N, states, p.tile);
   }
   BN_LAUNCH_CHECK("gather_rows");
@@ -661,10 +672,10 @@ int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream)
   const int64_t total = p.N * fa.fd.elems;
   const uint32_t blocks = (uint32_t)((total + 255) / 256);
   if (p.dtype == BN_F32) {
-    hipLaunchKernelGGL(bn::family_marginal<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+    bn::launch(bn::family_marginal<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
                        static_cast<const float*>(p.cpts), fa, static_cast<float*>(out_dev), p.N, p.tile);
   } else {
-    hipLaunchKernelGGL(bn::family_marginal<double>, dim3(blocks), dim3(256), 0, s,
+    bn::launch(bn::family_marginal<double>, dim3(blocks), dim3(256), 0, s,
                        static_cast<const double*>(p.arena), static_cast<const double*>(p.cpts), fa,
                        static_cast<double*>(out_dev), p.N, p.tile);
   }
@@ -699,7 +710,7 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
     if (used < 0) return fail(BN_ERR_HIP, "launch of ll_partial_listed failed");
     if (used > 0) {
       prof_begin("log_likelihood", (double)p.N * 8.0, s);
-      hipLaunchKernelGGL(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, used, average ? 1.0 / (double)p.N : 1.0,
+      bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, used, average ? 1.0 / (double)p.N : 1.0,
                          ll_out_dev);
       BN_LAUNCH_CHECK("sum_partials");
       prof_end(s);
@@ -714,6 +725,7 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
 
 int bn_profile_enable(int32_t enabled) {
   g_profiling.store(enabled != 0);
+  bn::launch_event_source() = enabled ? &next_launch_events : nullptr;
   return BN_OK;
 }
 
@@ -728,8 +740,18 @@ int bn_profile_report(char* buffer, int64_t capacity) {
   std::vector<double> total_ms, alg_bytes;
   std::vector<int64_t> launches;
   for (auto& r : records) {
-    float ms = 0.f;
-    if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+    double region_ms = 0.0;
+    bool ok = !r.events.empty();
+    for (size_t e = 0; e + 1 < r.events.size(); e += 2) {
+      float ms = 0.f;
+      if (hipEventSynchronize(r.events[e + 1]) == hipSuccess &&
+          hipEventElapsedTime(&ms, r.events[e], r.events[e + 1]) == hipSuccess) {
+        region_ms += ms;
+      } else {
+        ok = false;
+      }
+    }
+    if (ok) {
       size_t i = std::find(labels.begin(), labels.end(), r.label) - labels.begin();
       if (i == labels.size()) {
         labels.push_back(r.label);
@@ -737,12 +759,11 @@ int bn_profile_report(char* buffer, int64_t capacity) {
         launches.push_back(0);
         alg_bytes.push_back(r.alg_bytes);
       }
-      total_ms[i] += ms;
+      total_ms[i] += region_ms;
       launches[i] += 1;
     }
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    g_event_pool.push_back(r.start);
-    g_event_pool.push_back(r.stop);
+    for (hipEvent_t e : r.events) g_event_pool.push_back(e);
   }
   std::string json = "[";
   for (size_t i = 0; i < labels.size(); ++i) {

@@ -4,6 +4,7 @@
 // a launch failure.
 #pragma once
 
+#include "launch.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -276,13 +277,13 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
   const WideArgs a = wide_args(p, g, w, fresh);
   const bool fused = w.fused_fgroup >= 0;
   if (!fresh && (!fused || !w.partials_valid)) {
-    hipLaunchKernelGGL(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+    launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
     if (!launch_ok()) return false;
   }
-  hipLaunchKernelGGL(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles)), dim3(256), 0, s, arena, a);
+  launch(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles)), dim3(256), 0, s, arena, a);
   if (!launch_ok()) return false;
   if (!fused) {
-    hipLaunchKernelGGL(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+    launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
     if (!launch_ok()) return false;
   }
   return true;
@@ -367,7 +368,7 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
     VarSmallFn fn = g.num_inputs * g.num_states <= 12 ? var_small_lookup(g.num_inputs, g.num_states) : nullptr;
     if (fn) {
       // whole node in registers
-      hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c,
+      launch(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c,
                          K, p.ntiles, fresh);
       return launch_ok() ? 1 : -1;
     }
@@ -375,19 +376,19 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
     const dim3 grid(wave_blocks((int64_t)K * p.ntiles));
     switch (g.num_inputs) {
       case 1:
-        hipLaunchKernelGGL(variable_big_fast<1>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+        launch(variable_big_fast<1>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
                            p.ntiles, fresh);
         break;
       case 2:
-        hipLaunchKernelGGL(variable_big_fast<2>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+        launch(variable_big_fast<2>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
                            p.ntiles, fresh);
         break;
       case 3:
-        hipLaunchKernelGGL(variable_big_fast<3>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+        launch(variable_big_fast<3>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
                            p.ntiles, fresh);
         break;
       default:
-        hipLaunchKernelGGL(variable_big_fast<4>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
+        launch(variable_big_fast<4>, grid, dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c, K, g.num_states,
                            p.ntiles, fresh);
         break;
     }
@@ -449,7 +450,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.em_partial = fam.em_partial;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
-  hipLaunchKernelGGL(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
+  launch(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
     fam.pending = true;
@@ -503,7 +504,7 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
     const int64_t rows = n_listed + fam.ll_rows;
     const int32_t blocks = (int32_t)std::min<int64_t>(max_blocks - used, rows * ((p.npad + 255) / 256));
     if (blocks <= 0) return -1;
-    hipLaunchKernelGGL(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+    launch(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
                        st->d_ll_offs, n_listed, fam.ll_part, (int64_t)fam.ll_rows, p.N, p.npad, partial + used);
     if (!launch_ok()) return -1;
     used += blocks;
@@ -520,7 +521,7 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
   if (it == st->fused.end() || !it->second.em_ready) return 0;
   FactorGroup& g = p.fgroups[fi];
   const int64_t items = (int64_t)g.nodes.size() * g.cpt_elems;
-  hipLaunchKernelGGL(em_finalize_slots, dim3(wave_blocks(items)), dim3(256), 0, s, it->second.em_partial,
+  launch(em_finalize_slots, dim3(wave_blocks(items)), dim3(256), 0, s, it->second.em_partial,
                      static_cast<const float*>(p.cpts), g.d_cpt, (int32_t)g.nodes.size(), (int32_t)g.cpt_elems,
                      it->second.slots, accum);
   return launch_ok() ? 1 : -1;
@@ -548,7 +549,7 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       }
     }
     if (g.dims.size() == 1) {
-      hipLaunchKernelGGL(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
+      launch(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
                          p.ntiles);
       return launch_ok() ? 1 : -1;
     }
@@ -559,16 +560,16 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
         const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
         FactorP1Fn dense = d0 == 64 ? (sv == 64 ? factor_p1_mfma<64, 64> : factor_p1_mfma<64, 32>)
                                     : (sv == 64 ? factor_p1_mfma<32, 64> : factor_p1_mfma<32, 32>);
-        hipLaunchKernelGGL(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+        launch(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
         return launch_ok() ? 1 : -1;
       }
       FactorP1Fn fn = factor_p1_lookup(d0, sv);
       if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+      launch(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      hipLaunchKernelGGL((factor_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt,
+      launch((factor_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt,
                          K, p.ntiles);
       return launch_ok() ? 1 : -1;
     }
@@ -587,7 +588,7 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, d
     if (g.dims.size() == 1) {
       EmP1Fn fn = em_root_lookup(g.dims[0]);
       if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
+      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 2) {
@@ -595,17 +596,17 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, d
       if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
         EmP1Fn dense = d0 == 64 ? (sv == 64 ? em_p1_mfma<64, 64> : em_p1_mfma<64, 32>)
                                 : (sv == 64 ? em_p1_mfma<32, 64> : em_p1_mfma<32, 32>);
-        hipLaunchKernelGGL(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
+        launch(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
                            p.ntiles, nchunks, partial);
         return launch_ok() ? 1 : -1;
       }
       EmP1Fn fn = em_p1_lookup(g.dims[0], g.dims[1]);
       if (!fn) return 0;
-      hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
+      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      hipLaunchKernelGGL((em_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles,
+      launch((em_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles,
                          nchunks, partial);
       return launch_ok() ? 1 : -1;
     }
