@@ -176,9 +176,20 @@ void release(bn::Plan& p) {
   if (p.d_obs_states) (void)hipFree(p.d_obs_states);
   if (p.d_fill_off) (void)hipFree(p.d_fill_off);
   if (p.d_fill_states) (void)hipFree(p.d_fill_states);
+  if (p.d_row_off) (void)hipFree(p.d_row_off);
+  if (p.d_row_len) (void)hipFree(p.d_row_len);
 }
 
-int32_t em_chunks(const bn::Plan& p) {
+int32_t em_chunks(const bn::Plan& p, int64_t active_nodes = -1) {
+  if (active_nodes >= 0) {
+    // only `active_nodes` of the nodes go through the partial sums (the rest is served by the
+    // fused kernels' own sums): more chunks each, within the scratch that was allocated
+    const int64_t slices = p.ntiles * (p.tile / 64);
+    const int64_t room = p.cpt_total > 0 ? (p.scratch_elems - kLlBlocks) / p.cpt_total : 1;
+    int64_t want = (4096 + active_nodes - 1) / std::max<int64_t>(active_nodes, 1);
+    want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 256), room));
+    return (int32_t)std::min<int64_t>(want, slices);
+  }
   // enough (node, chunk) work items to fill the chip, never more chunks than 64-sample slices
   const int64_t slices = p.ntiles * (p.tile / 64);
   int64_t want = (4096 + p.n_nodes - 1) / p.n_nodes;
@@ -314,7 +325,10 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
   std::vector<const bn::FactorGroup*> reduced_groups;
   const T* arena = static_cast<const T*>(p.arena);
   const T* cpts = static_cast<const T*>(p.cpts);
-  const int32_t nchunks = em_chunks(p);
+  int64_t active_nodes = 0;
+  for (auto& g : p.fgroups)
+    if (!(use_reduced && bn::em_is_reduced(p, (size_t)(&g - p.fgroups.data())))) active_nodes += (int64_t)g.nodes.size();
+  const int32_t nchunks = active_nodes < p.n_nodes ? em_chunks(p, active_nodes) : em_chunks(p);
   double* partial = p.scratch + kLlBlocks;
   for (auto& g : p.fgroups) {
     const int32_t K = (int32_t)g.nodes.size();
@@ -420,7 +434,11 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
   p.device_bytes += p.arena_elems * (int64_t)p.elem_size;
   BN_TRY_HIP(hipMalloc(&p.cpts, (size_t)p.cpt_total * p.elem_size));
   p.device_bytes += p.cpt_total * (int64_t)p.elem_size;
-  p.scratch_elems = kLlBlocks + p.cpt_total * (int64_t)em_chunks(p) + bn::fast_scratch_elems(p);
+  {
+    // room for more chunks per entry when only a few nodes need partial sums (at most 32 MiB extra)
+    const int64_t generous = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)(4 << 20) / std::max<int64_t>(p.cpt_total, 1)));
+    p.scratch_elems = kLlBlocks + p.cpt_total * std::max<int64_t>(em_chunks(p), generous) + bn::fast_scratch_elems(p);
+  }
   BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.scratch), (size_t)p.scratch_elems * sizeof(double)));
   p.device_bytes += p.scratch_elems * 8;
 
@@ -473,6 +491,22 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY(upload(offs, &p.d_fill_off, p.device_bytes));
     BN_TRY(upload(sts, &p.d_fill_states, p.device_bytes));
   }
+  {
+    std::vector<int64_t> row_off;
+    std::vector<int32_t> row_len;
+    for (int32_t j = 0; j < p.n_nodes; ++j) {
+      const int32_t S = p.states[j];
+      int64_t elems = 1;
+      for (int32_t d : p.cpt_dims[j]) elems *= d;
+      for (int64_t r = 0; r < elems / S; ++r) {
+        row_off.push_back(p.cpt_off[j] + r * S);
+        row_len.push_back(S);
+      }
+    }
+    p.n_rows = (int64_t)row_off.size();
+    BN_TRY(upload(row_off, &p.d_row_off, p.device_bytes));
+    BN_TRY(upload(row_len, &p.d_row_len, p.device_bytes));
+  }
   BN_TRY(bn::prepare_fast(p));
   BN_TRY(p.dtype == BN_F32 ? reset_messages_t<float>(p, nullptr) : reset_messages_t<double>(p, nullptr));
   BN_TRY_HIP(hipStreamSynchronize(nullptr));
@@ -512,6 +546,7 @@ int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   BN_HIP_CHECK(hipMemcpyAsync(p.cpts, cpts_dev, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice,
                               static_cast<hipStream_t>(stream)));
   p.cpts_set = true;
+  bn::cpts_changed_fast(p);
   return BN_OK;
 }
 
@@ -535,7 +570,11 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
     if (!evidence_dev[i]) return fail(BN_ERR_INVALID, "an evidence pointer is null");
     max_states = std::max(max_states, p.states[p.observed[i]]);
   }
+  // same sources as last time: the device table is already right
+  const bool same_table = p.evidence_on_device.size() == count &&
+                          std::memcmp(p.evidence_on_device.data(), evidence_dev, count * sizeof(void*)) == 0;
   // next slot of the pinned staging ring; wait only if its previous upload is still in flight
+  if (!same_table) {
   const int32_t slot = p.staging_next;
   p.staging_next = (slot + 1) % bn::Plan::kStagingSlots;
   hipEvent_t slot_event = static_cast<hipEvent_t>(p.staging_events[slot]);
@@ -545,6 +584,8 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, staging, count * sizeof(void*), hipMemcpyHostToDevice, s));
   BN_HIP_CHECK(hipEventRecord(slot_event, s));
   p.staging_used[slot] = true;
+  p.evidence_on_device.assign(evidence_dev, evidence_dev + count);
+  }
   const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
   {
     double bytes = 0;
@@ -721,6 +762,27 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   }
   if (rc != BN_OK) return rc;
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
+}
+
+int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,
+              double regularization, void* new_cpts_dev, void* stream) {
+  if (!plan || !count_sums_dev || !new_cpts_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (learning_rate >= 0.0 && !old_cpts_dev) return fail(BN_ERR_INVALID, "old_cpts_dev is null but a learning rate is given");
+  if (regularization < 0.0 || regularization > 1.0) return fail(BN_ERR_INVALID, "regularization must be in [0, 1]");
+  bn::Plan& p = plan->p;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((uint32_t)((p.n_rows + 255) / 256));
+  prof_begin("m_step", 0.0, s);
+  if (p.dtype == BN_F32) {
+    bn::launch(bn::m_step_rows<float>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const float*>(old_cpts_dev),
+               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<float*>(new_cpts_dev));
+  } else {
+    bn::launch(bn::m_step_rows<double>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const double*>(old_cpts_dev),
+               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<double*>(new_cpts_dev));
+  }
+  BN_LAUNCH_CHECK("m_step_rows");
+  prof_end(s);
+  return BN_OK;
 }
 
 int bn_profile_enable(int32_t enabled) {

@@ -65,6 +65,9 @@ struct FastState {
   std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
   std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
   std::vector<char> vgroup_skip;              // variable groups whose every node a fused kernel serves
+  // parentless factor groups whose output (the prior, broadcast over observations) is already in
+  // place: it only changes with the CPTs
+  std::vector<char> root_written;
 };
 
 inline std::map<const Plan*, FastState>& fast_states() {
@@ -131,12 +134,18 @@ inline void invalidate_fast(Plan& p) {
       kv.second.pending = false;
       kv.second.em_ready = false;
     }
+    std::fill(st->root_written.begin(), st->root_written.end(), 0);
   }
+}
+
+inline void cpts_changed_fast(Plan& p) {
+  if (FastState* st = fast_state(p)) std::fill(st->root_written.begin(), st->root_written.end(), 0);
 }
 
 inline int prepare_fast(Plan& p) {
   FastState st;
   st.vgroup_skip.assign(p.vgroups.size(), 0);
+  st.root_written.assign(p.fgroups.size(), 0);
   if (p.dtype != 0) {
     fast_states()[&p] = std::move(st);
     return 0;
@@ -280,7 +289,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
     launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
     if (!launch_ok()) return false;
   }
-  launch(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles)), dim3(256), 0, s, arena, a);
+  launch(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles * (kTile / 64))), dim3(256), 0, s, arena, a);
   if (!launch_ok()) return false;
   if (!fused) {
     launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
@@ -549,9 +558,12 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       }
     }
     if (g.dims.size() == 1) {
+      if (st && st->root_written[fi]) return 1;
       launch(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
                          p.ntiles);
-      return launch_ok() ? 1 : -1;
+      if (!launch_ok()) return -1;
+      if (st) st->root_written[fi] = 1;
+      return 1;
     }
     if (g.dims.size() == 2) {
       const int32_t d0 = g.dims[0], sv = g.dims[1];

@@ -381,6 +381,37 @@ __global__ void __launch_bounds__(256) ll_partial(const T* __restrict__ c, int64
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// M-step, one thread per CPT row.  Products and sums are kept separate (no fused multiply-add),
+// so the result is the one the same formulas give when evaluated operation by operation.
+template <typename T>
+__global__ void __launch_bounds__(256) m_step_rows(const double* __restrict__ counts, const T* old_cpts,
+                                                  const int64_t* __restrict__ row_off,
+                                                  const int32_t* __restrict__ row_len, int64_t rows,
+                                                  double learning_rate, double regularization, T* out) {
+#pragma clang fp contract(off)
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t off = row_off[r];
+  const int32_t S = row_len[r];
+  double sum = 0.0;
+  for (int32_t j = 0; j < S; ++j) sum += counts[off + j];
+  const double uniform = 1.0 / (double)S;
+  for (int32_t j = 0; j < S; ++j) {
+    double x = counts[off + j] / sum;
+    if (regularization != 0.0) {
+      const double a = (1.0 - regularization) * x;
+      const double b = regularization * uniform;
+      x = a + b;
+    }
+    if (learning_rate >= 0.0) {
+      const double a = (1.0 - learning_rate) * (double)old_cpts[off + j];
+      const double b = learning_rate * x;
+      x = a + b;
+    }
+    out[off + j] = (T)x;
+  }
+}
+
 // Same sum when part of it already exists as per-observation partial sums: adds the normalisers
 // of the listed arrays (offsets into the arena, npad elements each) and `extra_rows` rows of
 // npad doubles.  grid.x = number of partials written

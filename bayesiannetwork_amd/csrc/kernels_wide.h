@@ -127,132 +127,107 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
   store_partial<S>(a, chunk, t, lane, m, e);
 }
 
+// One observation per lane, four waves per tile: the launch is short and latency-bound, so it
+// wants as many waves as it can get, and the partials of four chunks are requested together.
 template <int S>
 __global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (t >= a.ntiles) return;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= a.ntiles * (kTile / 64)) return;
+  const int64_t t = w / (kTile / 64);
+  const int32_t col = (int32_t)(w % (kTile / 64)) * 64 + lane;
+  const int64_t n = t * kTile + col;
 
-  double m[S][4];
-  int32_t e[S][4];
+  double m[S];
+  int32_t e[S];
 #pragma unroll
-  for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
-      m[s][v] = 1.0;
-      e[s][v] = 0;
-    }
-  if (a.fresh) {
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s)
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
-        m[s][v] = a.fresh_mant;
-        e[s][v] = a.fresh_exp;
-      }
+  for (int32_t s = 0; s < S; ++s) {
+    m[s] = a.fresh ? a.fresh_mant : 1.0;
+    e[s] = a.fresh ? a.fresh_exp : 0;
   }
-  for (int32_t ch = 0; ch < (a.fresh ? 0 : a.chunks); ++ch) {
+  // partial mantissas lie in [0.5, 1) (or are 0): a few dozen of them multiply without leaving
+  // double range, so one renormalisation per group of four loads is plenty
+  for (int32_t ch = 0; ch < (a.fresh ? 0 : a.chunks); ch += 4) {
+    double pm[4][S];
+    int32_t pe[4][S];
+#pragma unroll
+    for (int32_t u = 0; u < 4; ++u) {
+      const bool live = ch + u < a.chunks;
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) {
+        const int64_t row = ((int64_t)(live ? ch + u : ch) * S + s) * a.npad + n;
+        pm[u][s] = a.part_mant[row];
+        pe[u][s] = a.part_exp[row];
+        if (!live) {
+          pm[u][s] = 1.0;
+          pe[u][s] = 0;
+        }
+      }
+    }
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
-      const int64_t row = ((int64_t)ch * S + s) * a.npad + t * kTile + lane * 4;
-      const double2 lo = *reinterpret_cast<const double2*>(a.part_mant + row);
-      const double2 hi = *reinterpret_cast<const double2*>(a.part_mant + row + 2);
-      const int4 ex = *reinterpret_cast<const int4*>(a.part_exp + row);
-      m[s][0] *= lo.x;
-      m[s][1] *= lo.y;
-      m[s][2] *= hi.x;
-      m[s][3] *= hi.y;
-      e[s][0] += ex.x;
-      e[s][1] += ex.y;
-      e[s][2] += ex.z;
-      e[s][3] += ex.w;
+#pragma unroll
+      for (int32_t u = 0; u < 4; ++u) {
+        m[s] *= pm[u][s];
+        e[s] += pe[u][s];
+      }
+      int de = 0;
+      m[s] = frexp(m[s], &de);
+      e[s] += de;
     }
-    if ((ch & 3) == 3) renorm<S>(m, e);
   }
   // inputs no partial covers
   const float uniform = 1.0f / (float)S;
   for (int32_t u = 0; u < a.n_uncovered; ++u) {
     const int32_t i = a.uncovered[u];
     const bool skip = a.fresh && a.out_off[i] >= 0;
-    const float* src = arena + a.in_off[i];
+    const float* src = arena + a.in_off[i] + t * S * kTile + col;
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
-      f4 x;
-      if (skip) {
-        x = f4{{uniform, uniform, uniform, uniform}};
-      } else {
-        x = load4(src, t * S + s, lane);
-      }
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) m[s][v] *= (double)x.v[v];
+      const float x = skip ? uniform : src[s * kTile];
+      int de = 0;
+      m[s] = frexp(m[s] * (double)x, &de);
+      e[s] += de;
     }
-    renorm<S>(m, e);
   }
 
-  double z[4];
-#pragma unroll
-  for (int32_t v = 0; v < 4; ++v) {
-    int32_t emax = kDeadExponent;
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      int de = 0;
-      m[s][v] = frexp(m[s][v], &de);
-      e[s][v] = m[s][v] == 0.0 ? kDeadExponent : e[s][v] + de;
-      emax = e[s][v] > emax ? e[s][v] : emax;
-    }
-    z[v] = 0.0;
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      m[s][v] = ldexp(m[s][v], clamp_shift(e[s][v] - emax));  // P'[s]
-      z[v] += m[s][v];
-    }
-    e[0][v] = emax;
-  }
-  {
-    f4 c;
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) c.v[v] = (float)((double)e[0][v] * 0.6931471805599453 + log(z[v]));
-    store4(arena + a.c_off, t, lane, c);
-  }
+  int32_t emax = kDeadExponent;
 #pragma unroll
   for (int32_t s = 0; s < S; ++s) {
-    const int64_t row = (int64_t)s * a.npad + t * kTile + lane * 4;
-    *reinterpret_cast<double2*>(a.scaled + row) = make_double2(m[s][0], m[s][1]);
-    *reinterpret_cast<double2*>(a.scaled + row + 2) = make_double2(m[s][2], m[s][3]);
+    int de = 0;
+    m[s] = frexp(m[s], &de);
+    e[s] = m[s] == 0.0 ? kDeadExponent : e[s] + de;
+    emax = e[s] > emax ? e[s] : emax;
   }
+  double z = 0.0;
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s) {
+    m[s] = ldexp(m[s], clamp_shift(e[s] - emax));  // P'[s]
+    z += m[s];
+  }
+  arena[a.c_off + n] = (float)((double)emax * 0.6931471805599453 + log(z));
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s) a.scaled[(int64_t)s * a.npad + n] = m[s];
   // outgoing messages of the uncovered inputs
   for (int32_t u = 0; u < a.n_uncovered; ++u) {
     const int32_t i = a.uncovered[u];
     const int64_t dst = a.out_off[i];
     if (dst < 0) continue;
     const bool skip = a.fresh != 0;
-    const float* src = arena + a.in_off[i];
-    double q[S][4];
-    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* src = arena + a.in_off[i] + t * S * kTile + col;
+    double q[S];
+    double sum = 0.0;
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
-      f4 x;
-      if (skip) {
-        x = f4{{uniform, uniform, uniform, uniform}};
-      } else {
-        x = load4(src, t * S + s, lane);
-      }
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
-        q[s][v] = m[s][v] / (double)x.v[v];
-        sum[v] += q[s][v];
-      }
+      const float x = skip ? uniform : src[s * kTile];
+      q[s] = m[s] / (double)x;
+      sum += q[s];
     }
     const bool local = (i == a.I - 1);
+    sum = 1.0 / (local ? z : sum);
+    float* out = arena + dst + t * S * kTile + col;
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) sum[v] = 1.0 / (local ? z[v] : sum[v]);
-#pragma unroll
-    for (int32_t s = 0; s < S; ++s) {
-      f4 o;
-#pragma unroll
-      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(q[s][v] * sum[v]);
-      store4(arena + dst, t * S + s, lane, o);
-    }
+    for (int32_t s = 0; s < S; ++s) out[s * kTile] = (float)(q[s] * sum);
   }
 }
 

@@ -103,6 +103,11 @@ struct Plan {
   void* staging_events[kStagingSlots] = {};  // hipEvent_t
   bool staging_used[kStagingSlots] = {};
   int32_t staging_next = 0;
+  std::vector<const void*> evidence_on_device;  // the table d_evidence_ptrs holds (empty = nothing uploaded yet)
+  // CPT rows (last axis) of all nodes: start element in the flat CPT buffer and length
+  int64_t* d_row_off = nullptr;
+  int32_t* d_row_len = nullptr;
+  int64_t n_rows = 0;
   bool obs_all_pairs = false;  // float plan whose observed nodes all have two states
   bool c_stale = false;        // normalisers are to read as zero (reset since the last iteration)
   int64_t* d_obs_off = nullptr;

@@ -367,6 +367,32 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self.must_iterate = False
         return ll, counts
 
+    def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],
+               learning_rate: Optional[float], regularization: Optional[float]) -> torch.Tensor:
+        """New flat CPT buffer (network order, machine dtype) from flat float64 expected counts:
+        rows normalised, optionally blended with the uniform distribution (``regularization``) and
+        with ``old_flat`` (``learning_rate``) — the reference's ``_m_step`` formulas
+        (``optimizers/em_batch_optimizer.py:70-84``, ``optimizers/em_optimizer.py:57-63``) for all
+        nodes in one kernel."""
+        total = self._lib.bn_plan_cpt_elements(self._plan)
+        counts = count_sums.detach().to(self._device, torch.float64).contiguous().reshape(-1)
+        if counts.numel() != total:
+            raise ValueError("count_sums does not match the network the machine was built for")
+        old_ptr = None
+        if learning_rate is not None:
+            old = old_flat.detach().to(self._device, self._dtype).contiguous().reshape(-1)
+            if old.numel() != total:
+                raise ValueError("old_flat does not match the network the machine was built for")
+            old_ptr = ctypes.c_void_p(old.data_ptr())
+        out = torch.empty((total,), device=self._device, dtype=self._dtype)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_m_step(self._plan, ctypes.c_void_p(counts.data_ptr()), old_ptr,
+                                    -1.0 if learning_rate is None else float(learning_rate),
+                                    float(regularization or 0.0), ctypes.c_void_p(out.data_ptr()), self._stream())
+            )
+        return out
+
     def split_counts(self, flat: torch.Tensor) -> List[torch.Tensor]:
         views, pos = [], 0
         for shape in self._cpt_shapes:

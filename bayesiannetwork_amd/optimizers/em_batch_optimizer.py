@@ -59,7 +59,8 @@ class EmBatchOptimizer(IBatchOptimizer):
                     if count_sums is None:
                         count_sums = machine.expected_count_sums()
                     sums, ll, _ = reduce_statistics(machine, count_sums, ll, cfg.sharded)
-                    flat = flat_model.m_step(sums, flat, cfg.learning_rate, cfg.regularization)
+                    step = machine.m_step if hasattr(machine, "m_step") else flat_model.m_step
+                    flat = step(sums, flat, cfg.learning_rate, cfg.regularization)
                     flat_model.assign(flat)
                 else:
                     counts, ll = expected_counts(machine, self._network, cfg.sharded, ll)

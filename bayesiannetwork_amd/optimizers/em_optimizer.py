@@ -45,7 +45,8 @@ class EmOptimizer(IOptimizer):
                 if count_sums is None:
                     count_sums = machine.expected_count_sums()
                 sums, ll, _ = reduce_statistics(machine, count_sums, ll, self._settings.sharded)
-                flat_model.assign(flat_model.m_step(sums, None, None, None))
+                step = machine.m_step if hasattr(machine, "m_step") else flat_model.m_step
+                flat_model.assign(step(sums, None, None, None))
             else:
                 counts, ll = expected_counts(machine, self._network, self._settings.sharded, ll)
                 for node, p in zip(self._network.nodes, counts):

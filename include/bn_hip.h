@@ -164,6 +164,22 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
                      void* stream);
 
 /*
+ * M-step for the whole network in one launch.  For every CPT row (last axis) of every node:
+ *   target = count_sums_row / sum(count_sums_row)
+ *   target = (1 - regularization) * target + regularization / num_states      if regularization != 0
+ *   new    = (1 - learning_rate) * old + learning_rate * target               if learning_rate >= 0
+ *            target                                                          otherwise
+ * computed in double, written in the plan's dtype to new_cpts_dev (flat CPT layout, network
+ * order; may alias old_cpts_dev).  count_sums_dev is what bn_em_accumulate / bn_em_statistics
+ * wrote (any positive common scale: sums or means); old_cpts_dev is read only when
+ * learning_rate >= 0.  Does not touch the plan's own CPT snapshot: pass the result to
+ * bn_set_cpts (a new machine does).  Replaces EmBatchOptimizer._m_step
+ * (optimizers/em_batch_optimizer.py:70-84) and EmOptimizer._m_step (optimizers/em_optimizer.py:57-63).
+ */
+int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,
+              double regularization, void* new_cpts_dev, void* stream);
+
+/*
  * Inspection: copy one message out as [N, S].
  *   owner      node whose factor is one end of the edge
  *   slot       -1 = edge to the owner's own variable, p >= 0 = edge to its p-th parent,
@@ -177,7 +193,8 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
 
 /*
  * Per-kernel timing for benchmarks (process-wide switch): while enabled, every kernel any
- * plan launches is bracketed by hipEvents recorded on the launch stream.
+ * plan launches carries a start/stop hipEvent pair attached to its dispatch (no marker
+ * packets are put between kernels).
  * bn_profile_report waits for the recorded events, writes a JSON array
  *   [{"kernel": "...", "launches": n, "total_ms": x, "alg_bytes": b}, ...]
  * (NUL-terminated; "[]" if it does not fit) and clears the records.  alg_bytes is the

@@ -166,3 +166,44 @@ def test_em_statistics_equals_separate_calls_and_leaves_queries_intact(name):
     l2, c2 = fused.em_statistics()
     np.testing.assert_allclose(l2.item(), plain.log_likelihood_tensor().item(), rtol=1e-7)
     np.testing.assert_allclose(c2.cpu().numpy(), plain.expected_count_sums().cpu().numpy(), rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("lr,reg", [(None, None), (0.1, 0.01), (0.3, None), (None, 0.05)])
+def test_m_step_kernel_equals_the_tensor_formulas(dtype, lr, reg):
+    """bn_m_step against the same M-step written with torch tensor operations (FlatModel.m_step,
+    itself checked on the CPU against the per-node reference formulas).  Rows of two states sum in
+    one order only, so they must agree bit for bit; longer rows within 1e-15 relative in float64
+    (summation order), one float32 ulp otherwise."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    torch.manual_seed(3)
+    q = Node.random((5,), ts, "Q")
+    mids = [Node.random((5, 3), ts, f"M{i}") for i in range(3)]
+    ys = [Node.random((3, 2), ts, f"Y{i}") for i in range(6)]
+    b = BayesianNetworkBuilder().add_node(q).add_nodes(mids, q)
+    for i, y in enumerate(ys):
+        b.add_node(y, mids[i % 3])
+    net = b.build()
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), net, ys, 8)
+    model = FlatModel(net)
+    old = model.gather()
+    counts = torch.rand(old.numel(), dtype=torch.float64, device=old.device) * 7 + 0.01
+    want = model.m_step(counts, old, lr, reg)
+    got = machine.m_step(counts, old, lr, reg)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    pos = 0
+    for shape in model.shapes:
+        size = int(np.prod(shape))
+        w, g = want[pos:pos + size], got[pos:pos + size]
+        if shape[-1] == 2:
+            assert torch.equal(w, g), shape
+        else:
+            torch.testing.assert_close(g, w, rtol=1e-15 if dtype == "float64" else 1.2e-7, atol=0)
+        pos += size
+    rows = torch.cat([v.reshape(-1, v.shape[-1]).sum(-1) for v in model.views(got)])
+    torch.testing.assert_close(rows, torch.ones_like(rows), rtol=0, atol=1e-6 if dtype == "float32" else 1e-14)
