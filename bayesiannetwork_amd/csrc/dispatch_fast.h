@@ -434,9 +434,16 @@ inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
 
 inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, float* arena, const float* cpts,
                               int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s) {
-  LeafFamilyFn fn = mode == kLeafFull     ? leaf_family_lookup<kLeafFull>(g.dims[0], g.dims[1])
-                    : mode == kLeafReduce ? leaf_family_lookup<kLeafReduce>(g.dims[0], g.dims[1])
-                                          : leaf_family_lookup<kLeafLoop>(g.dims[0], g.dims[1]);
+  const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+  LeafFamilyFn fn = nullptr;
+  switch (mode + 3 * state) {
+#define X(M)                                              \
+  case M:                                                 \
+    fn = leaf_family_lookup<M>(g.dims[0], g.dims[1]);     \
+    break;
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+  }
   if (!fn) return -1;
   LeafFamilyArgs a;
   a.f_in = g.d_in;

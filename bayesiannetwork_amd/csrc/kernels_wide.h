@@ -321,6 +321,12 @@ struct LeafFamilyArgs {
 //                of c = log z over each chunk's families and for the per-wave EM count sums.  The stored state stays one iteration behind, and the
 //                host re-runs this iteration in kLeafFull mode if anything asks for messages.
 constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
+// Where the iteration's input state comes from, also a compile-time choice (folded into the
+// kernel's MODE template argument as MODE = mode + 3 * state):
+//   kLeafSteady      the loop state a kLeafLoop launch left (z_state);
+//   kLeafFresh       nothing has been sent yet: every message still has its initial uniform value;
+//   kLeafFromArrays  the message arrays a kLeafFull launch wrote.
+constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2;
 
 // Sum over the 64 lanes with data-parallel-primitive adds only (no LDS crossbar): quad swaps,
 // row (16-lane) mirrors, then the row broadcasts.  The total ends up in lane 63.
@@ -427,31 +433,37 @@ __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const f
   return p;
 }
 
-// z of one leaf from its evidence and the factor's previous message, rounded to float
+// z of one leaf from its evidence and the factor's previous message
 template <int S, int V>
 __device__ __forceinline__ fv<V> leaf_normaliser(const fv<V>* ev, const fv<V>* from_factor) {
   fv<V> z;
 #pragma unroll
   for (int32_t v = 0; v < V; ++v) {
-    double acc = 0.0;
+    float acc = 0.f;
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) acc = fma((double)ev[j].v[v], (double)from_factor[j].v[v], acc);
-    z.v[v] = (float)acc;
+    for (int32_t j = 0; j < S; ++j) acc = fmaf(ev[j].v[v], from_factor[j].v[v], acc);
+    z.v[v] = acc;
   }
   return z;
 }
 
-template <int S, int V>
+// 1/x to within an ulp: hardware seed plus one Newton step
+__device__ __forceinline__ float recipf(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.f), r, r);
+}
+
+template <int S, int V, int STATE>
 __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const LeafFamilyArgs& a, int64_t t,
                                                       int32_t col) {
   LeafState<S, V> st;
 #pragma unroll
   for (int32_t j = 0; j < S; ++j) st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
-  if (a.fresh || a.prev_from_arrays) {
+  if constexpr (STATE != kLeafSteady) {
     fv<V> own[S];
 #pragma unroll
     for (int32_t j = 0; j < S; ++j)
-      own[j] = a.fresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
+      own[j] = STATE == kLeafFresh ? splat<V>(1.0f / (float)S) : loadv<V>(p.f2v_own, t * S + j, col);
     st.z = leaf_normaliser<S, V>(st.ev, own);
   } else {
     st.z = loadv<V>(p.z, t, col);
@@ -462,8 +474,9 @@ __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const L
 template <int D0, int S, int V, int MODE>
 __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      LeafFamilyArgs a) {
-  constexpr bool FULL = MODE == kLeafFull;
-  constexpr bool REDUCE = MODE == kLeafReduce;
+  constexpr bool FULL = MODE % 3 == kLeafFull;
+  constexpr bool REDUCE = MODE % 3 == kLeafReduce;
+  constexpr int32_t STATE = MODE / 3;
   constexpr int32_t kParts = 4 / V;
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -519,11 +532,11 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
   for (int32_t v = 0; v < V; ++v) ll_acc[v] = 0.0;
   LeafPtrs ptr = leaf_ptrs(arena, cpts, a, first);
-  LeafState<S, V> cur = leaf_state<S, V>(ptr, a, t, col);
+  LeafState<S, V> cur = leaf_state<S, V, STATE>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
     const int32_t kn = k + 1 < last ? k + 1 : k;
     const LeafPtrs ptr_next = leaf_ptrs(arena, cpts, a, kn);
-    const LeafState<S, V> nxt = leaf_state<S, V>(ptr_next, a, t, col);
+    const LeafState<S, V> nxt = leaf_state<S, V, STATE>(ptr_next, a, t, col);
     const float* cpt = ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the
@@ -547,9 +560,9 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
         fv<V> prev;
-        if (a.fresh) {
+        if constexpr (STATE == kLeafFresh) {
           prev = splat<V>(1.0f / (float)D0);
-        } else if (a.prev_from_arrays) {
+        } else if constexpr (STATE == kLeafFromArrays) {
           prev = loadv<V>(ptr.f2v_par, t * D0 + i, col);
         } else {
           prev = q[i];
@@ -566,7 +579,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     // own (leaf) variable: c = log z, message to the factor = ev / z
     float inv_z[V];
 #pragma unroll
-    for (int32_t v = 0; v < V; ++v) inv_z[v] = (float)recip((double)cur.z.v[v]);
+    for (int32_t v = 0; v < V; ++v) inv_z[v] = recipf(cur.z.v[v]);
     if (FULL || REDUCE) {
       fv<V> c;
 #pragma unroll
