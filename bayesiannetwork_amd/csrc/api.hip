@@ -84,6 +84,7 @@ std::mutex g_prof_mutex;
 std::vector<ProfRecord> g_prof;
 std::atomic<bool> g_profiling{false};
 bool g_region_open = false;
+std::string g_prof_prefix;  // only labels starting with this are timed
 
 std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than using it
 
@@ -112,6 +113,7 @@ bool next_launch_events(hipEvent_t* start, hipEvent_t* stop) {
 void prof_begin(const std::string& label, double alg_bytes, hipStream_t) {
   if (!g_profiling.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
+  if (!g_prof_prefix.empty() && label.compare(0, g_prof_prefix.size(), g_prof_prefix) != 0) return;
   ProfRecord r;
   r.label = label;
   r.alg_bytes = alg_bytes;
@@ -507,6 +509,16 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY(upload(row_off, &p.d_row_off, p.device_bytes));
     BN_TRY(upload(row_len, &p.d_row_len, p.device_bytes));
   }
+  if (p.ones_off >= 0) {
+    const int64_t count = (int64_t)p.ones_states * p.npad;
+    const dim3 grid((uint32_t)((count + 255) / 256));
+    if (p.dtype == BN_F32) {
+      bn::launch(bn::fill_region<float>, grid, dim3(256), 0, nullptr, static_cast<float*>(p.arena) + p.ones_off, count, 1.0f);
+    } else {
+      bn::launch(bn::fill_region<double>, grid, dim3(256), 0, nullptr, static_cast<double*>(p.arena) + p.ones_off, count, 1.0);
+    }
+    BN_TRY_HIP(hipGetLastError());
+  }
   BN_TRY(bn::prepare_fast(p));
   BN_TRY(p.dtype == BN_F32 ? reset_messages_t<float>(p, nullptr) : reset_messages_t<double>(p, nullptr));
   BN_TRY_HIP(hipStreamSynchronize(nullptr));
@@ -788,6 +800,12 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
 int bn_profile_enable(int32_t enabled) {
   g_profiling.store(enabled != 0);
   bn::launch_event_source() = enabled ? &next_launch_events : nullptr;
+  return BN_OK;
+}
+
+int bn_profile_only(const char* label_prefix) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof_prefix = label_prefix ? label_prefix : "";
   return BN_OK;
 }
 

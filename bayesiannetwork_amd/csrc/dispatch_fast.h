@@ -193,7 +193,7 @@ inline int prepare_fast(Plan& p) {
     fam.wide_index = wit->second;
     std::vector<int64_t> obs, cs;
     for (int32_t j : g.nodes) {
-      obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : -1);
+      obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : p.ones_off);
       cs.push_back(p.c_off[j]);
       handled[j] = 1;
     }

@@ -408,7 +408,7 @@ struct LeafPtrs {  // wave-uniform
   float* v2f_own;
   float* c;
   float* z;          // loop-state normaliser of this family
-  const float* obs;  // nullptr = not observed
+  const float* obs;  // the observation, or an all-ones array when the leaf is not observed
   const float* cpt;
 };
 
@@ -427,8 +427,7 @@ __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const f
   p.v2f_own = arena + a.f_in[2 * k + 1];
   p.c = arena + a.c_off[k];
   p.z = a.z_state + (int64_t)k * a.npad;
-  const int64_t obs = a.obs_off[k];
-  p.obs = obs >= 0 ? arena + obs : nullptr;
+  p.obs = arena + a.obs_off[k];
   p.cpt = cpts + a.cpt_off[k];
   return p;
 }
@@ -458,7 +457,7 @@ __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const L
                                                       int32_t col) {
   LeafState<S, V> st;
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) st.ev[j] = p.obs ? loadv<V>(p.obs, t * S + j, col) : splat<V>(1.f);
+  for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<V>(p.obs, t * S + j, col);
   if constexpr (STATE != kLeafSteady) {
     fv<V> own[S];
 #pragma unroll

@@ -159,6 +159,15 @@ std::string compile_plan(Plan& p, int dtype, int64_t num_observations, int32_t n
   p.c_base = cursor;
   p.c_off.resize(num_nodes);
   for (int32_t j = 0; j < num_nodes; ++j) p.c_off[j] = take(1);
+  // an all-ones array that stands in for the observation of unobserved childless nodes, so that
+  // kernels serving observed and unobserved leaves alike read both the same way
+  {
+    int32_t widest = 0;
+    for (int32_t j = 0; j < num_nodes; ++j)
+      if (p.children[j].empty() && p.observed_slot_of[j] < 0) widest = std::max(widest, p.states[j]);
+    p.ones_off = widest > 0 ? take(widest) : -1;
+    p.ones_states = widest;
+  }
   p.arena_elems = cursor;
 
   // ---- variable groups

@@ -108,6 +108,8 @@ struct Plan {
   int64_t* d_row_off = nullptr;
   int32_t* d_row_len = nullptr;
   int64_t n_rows = 0;
+  int64_t ones_off = -1;  // arena offset of ones_states * npad elements equal to 1 (never written after creation), or -1
+  int32_t ones_states = 0;
   bool obs_all_pairs = false;  // float plan whose observed nodes all have two states
   bool c_stale = false;        // normalisers are to read as zero (reset since the last iteration)
   int64_t* d_obs_off = nullptr;

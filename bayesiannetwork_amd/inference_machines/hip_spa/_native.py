@@ -71,6 +71,8 @@ def _declare(lib):
     lib.bn_get_message.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.bn_profile_enable.restype = c_int
     lib.bn_profile_enable.argtypes = [c_int32]
+    lib.bn_profile_only.restype = c_int
+    lib.bn_profile_only.argtypes = [c_char_p]
     lib.bn_profile_report.restype = c_int
     lib.bn_profile_report.argtypes = [c_char_p, c_int64]
 
@@ -80,7 +82,7 @@ EXPORTS = (
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_m_step", "bn_get_message",
-    "bn_profile_enable", "bn_profile_report",
+    "bn_profile_enable", "bn_profile_report", "bn_profile_only",
 )
 
 

@@ -78,9 +78,12 @@ class _FactorGraphView:
         return self._G
 
 
-def enable_profiling(enabled: bool = True) -> None:
-    """Process-wide: bracket every kernel launch with HIP events (benchmark use)."""
-    _native.check(_native.load().bn_profile_enable(1 if enabled else 0))
+def enable_profiling(enabled: bool = True, only: Optional[str] = None) -> None:
+    """Process-wide: time every kernel launch with HIP events attached to its dispatch (benchmark
+    use); ``only`` restricts the timing to kernels whose report label starts with it."""
+    lib = _native.load()
+    _native.check(lib.bn_profile_only(only.encode() if only else None))
+    _native.check(lib.bn_profile_enable(1 if enabled else 0))
 
 
 def profile_report():
@@ -158,7 +161,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self._n = max(int(num_observations), 1)
 
         pool = bayesian_network.__dict__.setdefault("_hip_plan_pool", {})
-        key = (tuple(id(o) for o in self.observed_nodes), self._n, self._dtype, str(self._device))
+        key = (tuple(map(id, self.observed_nodes)), self._n, self._dtype, self._device)
         topo = pool.get(key)
         if topo is None:
             topo = pool[key] = _Topology(bayesian_network, self.observed_nodes)

@@ -204,6 +204,12 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
  */
 int bn_profile_enable(int32_t enabled);
 int bn_profile_report(char* buffer, int64_t capacity);
+/*
+ * Restrict the timing to kernels whose report label starts with label_prefix (NULL or "" = all
+ * kernels again).  A timed dispatch costs a few microseconds more than an untimed one, so a
+ * benchmark that wants one kernel's durations from inside its timed region limits the timing to it.
+ */
+int bn_profile_only(const char* label_prefix);
 
 #ifdef __cplusplus
 }
