@@ -231,6 +231,8 @@ inline int prepare_fast(Plan& p) {
     int64_t want = std::max<int64_t>(1, (6144 + p.ntiles) / (2 * p.ntiles));
     if (getenv("BN_WIDE_CHUNKS")) want = atoi(getenv("BN_WIDE_CHUNKS"));
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
+    // the leaf-family kernel keeps a chunk's exponents in 16 bits
+    if (w.fused_fgroup >= 0) chunks = std::max(chunks, (n + kLeafMaxChunkLen - 1) / kLeafMaxChunkLen);
     w.chunk_len = (n + chunks - 1) / chunks;
     w.chunks = (n + w.chunk_len - 1) / w.chunk_len;
     if (!dev_upload(w.covered, &w.d_covered, p.device_bytes) || !dev_upload(w.uncovered, &w.d_uncovered, p.device_bytes))

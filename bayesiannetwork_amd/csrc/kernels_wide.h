@@ -352,55 +352,43 @@ __device__ __forceinline__ double recip(double x) {
   return fma(fma(-x, r, 1.0), r, r);
 }
 
+// V floats of one lane as a hardware vector: arithmetic on it compiles to the packed
+// two-float instructions (v_pk_mul/add/fma_f32) when V is even.
 template <int V>
-struct fv {
-  float v[V];
-};
+using fv = float __attribute__((ext_vector_type(V)));
 
 template <int V>
 __device__ __forceinline__ fv<V> loadv(const float* __restrict__ base, int64_t row, int32_t col) {
-  fv<V> r;
-  if constexpr (V == 4) {
-    const float4 x = *reinterpret_cast<const float4*>(base + row * kTile + col);
-    r.v[0] = x.x;
-    r.v[1] = x.y;
-    r.v[2] = x.z;
-    r.v[3] = x.w;
-  } else if constexpr (V == 2) {
-    const float2 x = *reinterpret_cast<const float2*>(base + row * kTile + col);
-    r.v[0] = x.x;
-    r.v[1] = x.y;
-  } else {
-    r.v[0] = base[row * kTile + col];
-  }
-  return r;
+  return *reinterpret_cast<const fv<V>*>(base + row * kTile + col);
 }
 
 template <int V>
 __device__ __forceinline__ void storev(float* __restrict__ base, int64_t row, int32_t col, const fv<V>& r) {
-  if constexpr (V == 4) {
-    *reinterpret_cast<float4*>(base + row * kTile + col) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
-  } else if constexpr (V == 2) {
-    *reinterpret_cast<float2*>(base + row * kTile + col) = make_float2(r.v[0], r.v[1]);
-  } else {
-    base[row * kTile + col] = r.v[0];
-  }
+  *reinterpret_cast<fv<V>*>(base + row * kTile + col) = r;
 }
 
 template <int V>
 __device__ __forceinline__ fv<V> splat(float x) {
   fv<V> r;
 #pragma unroll
-  for (int32_t v = 0; v < V; ++v) r.v[v] = x;
+  for (int32_t v = 0; v < V; ++v) r[v] = x;
+  return r;
+}
+
+template <int V>
+__device__ __forceinline__ fv<V> rcpv(const fv<V>& x) {
+  fv<V> r;
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) r[v] = __builtin_amdgcn_rcpf(x[v]);
   return r;
 }
 
 // V observations per lane: a wave covers 64*V observations, i.e. 4/V work items per tile.
 //
 // The loop over the chunk's families is software-pipelined by hand: the small loop state of
-// family k+1 (its pointers, previous own message, observation, previous normaliser) is
-// requested before the arithmetic of family k, so that with two waves per SIMD the memory
-// latency of one family hides behind the arithmetic of the previous one.
+// family k+1 (its pointers, observation, normaliser) is requested before the arithmetic of
+// family k, so that with a few waves per SIMD the memory latency of one family hides behind the
+// arithmetic of the previous one.
 struct LeafPtrs {  // wave-uniform
   float* f2v_par;
   float* f2v_own;
@@ -435,21 +423,17 @@ __device__ __forceinline__ LeafPtrs leaf_ptrs(float* __restrict__ arena, const f
 // z of one leaf from its evidence and the factor's previous message
 template <int S, int V>
 __device__ __forceinline__ fv<V> leaf_normaliser(const fv<V>* ev, const fv<V>* from_factor) {
-  fv<V> z;
+  fv<V> z = ev[0] * from_factor[0];
 #pragma unroll
-  for (int32_t v = 0; v < V; ++v) {
-    float acc = 0.f;
-#pragma unroll
-    for (int32_t j = 0; j < S; ++j) acc = fmaf(ev[j].v[v], from_factor[j].v[v], acc);
-    z.v[v] = acc;
-  }
+  for (int32_t j = 1; j < S; ++j) z = __builtin_elementwise_fma(ev[j], from_factor[j], z);
   return z;
 }
 
 // 1/x to within an ulp: hardware seed plus one Newton step
-__device__ __forceinline__ float recipf(float x) {
-  const float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(fmaf(-x, r, 1.f), r, r);
+template <int V>
+__device__ __forceinline__ fv<V> recipv(const fv<V>& x) {
+  const fv<V> r = rcpv<V>(x);
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, splat<V>(1.f)), r, r);
 }
 
 template <int S, int V, int STATE>
@@ -470,6 +454,13 @@ __device__ __forceinline__ LeafState<S, V> leaf_state(const LeafPtrs& p, const L
   return st;
 }
 
+// The partial product's exponents, one per (state, observation): int16 pairs when V is 2 (packed
+// adds, half the registers; chunks are capped at kLeafMaxChunkLen families so that even messages
+// at the bottom of the float range cannot overflow 16 bits), plain int32 otherwise.
+constexpr int32_t kLeafMaxChunkLen = 192;
+template <int V>
+using ev_t = typename std::conditional<V == 2, short, int32_t>::type __attribute__((ext_vector_type(V)));
+
 template <int D0, int S, int V, int MODE>
 __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      LeafFamilyArgs a) {
@@ -487,7 +478,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   const int32_t col = part * 64 * V + lane * V;  // first observation of this lane inside the tile
 
   double pm[D0][V];
-  int32_t pe[D0][V];
+  ev_t<V> pe[D0];
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s)
 #pragma unroll
@@ -502,7 +493,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   // The parent's scaled product P' (largest state = 1) for this lane's observations, in float.
   // A state whose share is below float range reads as zero: its message to a leaf factor would
   // be below 2^-100 of the leading state's and cannot change any sum it enters.
-  float pf[D0][V];
+  fv<V> pf[D0];
   {
     const double* scaled = a.scaled + t * kTile + col;
 #pragma unroll
@@ -544,82 +535,65 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     fv<V> q[D0];
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i) {
-      q[i] = splat<V>(0.f);
+      q[i] = cpt[i * S] * cur.ev[0];
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) q[i].v[v] = fmaf(cpt[i * S + j], cur.ev[j].v[v], q[i].v[v]);
+      for (int32_t j = 1; j < S; ++j) q[i] = __builtin_elementwise_fma(splat<V>(cpt[i * S + j]), cur.ev[j], q[i]);
     }
     // parent's message to this factor, before normalisation: r = P' / (previous message to the parent)
     fv<V> r[D0];
-    float inv_sum[V];
-    {
+    fv<V> inv_sum = splat<V>(0.f);
 #pragma unroll
-      for (int32_t v = 0; v < V; ++v) inv_sum[v] = 0.f;
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i) {
-        fv<V> prev;
-        if constexpr (STATE == kLeafFresh) {
-          prev = splat<V>(1.0f / (float)D0);
-        } else if constexpr (STATE == kLeafFromArrays) {
-          prev = loadv<V>(ptr.f2v_par, t * D0 + i, col);
-        } else {
-          prev = q[i];
-        }
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          r[i].v[v] = pf[i][v] * __builtin_amdgcn_rcpf(prev.v[v]);
-          inv_sum[v] += r[i].v[v];
-        }
+    for (int32_t i = 0; i < D0; ++i) {
+      fv<V> prev;
+      if constexpr (STATE == kLeafFresh) {
+        prev = splat<V>(1.0f / (float)D0);
+      } else if constexpr (STATE == kLeafFromArrays) {
+        prev = loadv<V>(ptr.f2v_par, t * D0 + i, col);
+      } else {
+        prev = q[i];
       }
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) inv_sum[v] = __builtin_amdgcn_rcpf(inv_sum[v]);
+      r[i] = pf[i] * rcpv<V>(prev);
+      inv_sum += r[i];
     }
+    inv_sum = rcpv<V>(inv_sum);
     // own (leaf) variable: c = log z, message to the factor = ev / z
-    float inv_z[V];
-#pragma unroll
-    for (int32_t v = 0; v < V; ++v) inv_z[v] = recipf(cur.z.v[v]);
+    const fv<V> inv_z = recipv<V>(cur.z);
     if (FULL || REDUCE) {
       fv<V> c;
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         int de = 0;
-        const float mz = frexpf(cur.z.v[v], &de);
-        c.v[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
-        if (REDUCE) ll_acc[v] += (double)c.v[v];
+        const float mz = frexpf(cur.z[v], &de);
+        c[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
+        if (REDUCE) ll_acc[v] += (double)c[v];
       }
       if (FULL) storev<V>(ptr.c, t, col, c);
     }
     fv<V> new_par[D0], new_own[S];
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) new_par[i].v[v] = q[i].v[v] * inv_z[v];
+    for (int32_t i = 0; i < D0; ++i) new_par[i] = q[i] * inv_z;
     if constexpr (FULL || REDUCE) {
       fv<V> to_f_own[S];
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j)
+      for (int32_t j = 0; j < S; ++j) to_f_own[j] = cur.ev[j] * inv_z;
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) to_f_own[j].v[v] = cur.ev[j].v[v] * inv_z[v];
-#pragma unroll
-      for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) r[i].v[v] *= inv_sum[v];  // now the normalised message
+      for (int32_t i = 0; i < D0; ++i) r[i] *= inv_sum;  // now the normalised message
       if constexpr (REDUCE) {
         // EM counts of this family over the wave's observations (padding masked), wave-reduced
 #pragma unroll
         for (int32_t j = 0; j < S; ++j)
 #pragma unroll
           for (int32_t v = 0; v < V; ++v)
-            if (t * kTile + col + v >= a.N) to_f_own[j].v[v] = 0.f;
+            if (t * kTile + col + v >= a.N) to_f_own[j][v] = 0.f;
         float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
 #pragma unroll
         for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
           for (int32_t j = 0; j < S; ++j) {
-            float x = 0.f;
+            const fv<V> prod = r[i] * to_f_own[j];
+            float x = prod[0];
 #pragma unroll
-            for (int32_t v = 0; v < V; ++v) x = fmaf(r[i].v[v], to_f_own[j].v[v], x);
+            for (int32_t v = 1; v < V; ++v) x += prod[v];
             x = wave_sum_lane63(x);
             if (lane == 63) dst[(int64_t)(i * S + j) * a.slots] = x;
           }
@@ -636,38 +610,37 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     }
     // factor's message to the leaf: cpt^T . (normalised message from the parent)
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) new_own[j] = splat<V>(0.f);
+    for (int32_t j = 0; j < S; ++j) new_own[j] = cpt[j] * r[0];
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i)
+    for (int32_t i = 1; i < D0; ++i)
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) new_own[j].v[v] = fmaf(cpt[i * S + j], r[i].v[v], new_own[j].v[v]);
+      for (int32_t j = 0; j < S; ++j) new_own[j] = __builtin_elementwise_fma(splat<V>(cpt[i * S + j]), r[i], new_own[j]);
     if (FULL) {
 #pragma unroll
       for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
     } else {
       // r was left un-normalised in loop mode: one scale of the S sums instead of D0 messages
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j)
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) new_own[j].v[v] *= inv_sum[v];
+      for (int32_t j = 0; j < S; ++j) new_own[j] *= inv_sum;
       storev<V>(ptr.z, t, col, leaf_normaliser<S, V>(cur.ev, new_own));
     }
     // fold into the partial product for the parent's next combine
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
-      for (int32_t v = 0; v < V; ++v) pm[i][v] *= (double)new_par[i].v[v];
+      for (int32_t v = 0; v < V; ++v) pm[i][v] *= (double)new_par[i][v];
     if (((k - first) & 3) == 3) {
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i)
+      for (int32_t i = 0; i < D0; ++i) {
+        ev_t<V> de_v;
 #pragma unroll
         for (int32_t v = 0; v < V; ++v) {
           int de = 0;
           pm[i][v] = frexp(pm[i][v], &de);
-          pe[i][v] += de;
+          de_v[v] = de;
         }
+        pe[i] += de_v;
+      }
     }
     ptr = ptr_next;
     cur = nxt;
@@ -680,23 +653,24 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   }
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
+    int32_t ex[V];
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {
       int de = 0;
       pm[s][v] = frexp(pm[s][v], &de);
-      pe[s][v] += de;
+      ex[v] = (int32_t)pe[s][v] + de;
     }
     const int64_t row = ((int64_t)chunk * D0 + s) * a.npad + t * kTile + col;
     if constexpr (V == 4) {
       *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
       *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(pm[s][2], pm[s][3]);
-      *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(pe[s][0], pe[s][1], pe[s][2], pe[s][3]);
+      *reinterpret_cast<int4*>(a.part_exp + row) = make_int4(ex[0], ex[1], ex[2], ex[3]);
     } else if constexpr (V == 2) {
       *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
-      *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(pe[s][0], pe[s][1]);
+      *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(ex[0], ex[1]);
     } else {
       a.part_mant[row] = pm[s][0];
-      a.part_exp[row] = pe[s][0];
+      a.part_exp[row] = ex[0];
     }
   }
 }

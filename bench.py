@@ -45,7 +45,10 @@ def pmc_traffic(kernel_label: str):
     if stem is None:
         return None
     hits = [v for k, v in table.items() if k.startswith(stem)]
-    return max(h["hbm_bytes_per_launch"] for h in hits) if hits else None
+    if not hits:
+        return None
+    # a label can cover several instantiations (loop / reduce modes): launch-weighted mean
+    return sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / sum(h["launches"] for h in hits)
 
 
 def build_model(ts, model: str, num_pixels: int = 784):
