@@ -226,9 +226,10 @@ inline int prepare_fast(Plan& p) {
       w.uncovered = {w.I - 2, w.I - 1};
     }
     const int32_t n = (int32_t)w.covered.size();
-    // about three rounds of resident waves (2 per SIMD x 1024 SIMDs) per launch: measured best on
-    // the 784-leaf model between 4 and 26 chunks
-    int64_t want = std::max<int64_t>(1, (6144 + p.ntiles) / (2 * p.ntiles));
+    // one round of resident waves (4 per SIMD x 1024 SIMDs) per launch, never a partly filled
+    // second one: measured best on the 784-leaf model (8 chunks at 60 000 observations; 7 and 9
+    // are both 5 % slower, 13 and more pay in the combine)
+    int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * (4 / kLeafVec)));
     if (getenv("BN_WIDE_CHUNKS")) want = atoi(getenv("BN_WIDE_CHUNKS"));
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
     // the leaf-family kernel keeps a chunk's exponents in 16 bits
