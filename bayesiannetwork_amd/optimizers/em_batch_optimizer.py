@@ -54,7 +54,7 @@ class EmBatchOptimizer(IBatchOptimizer):
                 if hasattr(machine, "expected_count_sums"):
                     # whole-network M-step on one flat buffer; nodes get views of it
                     if flat_model is None:
-                        flat_model = FlatModel(self._network)
+                        flat_model = FlatModel.of(self._network)
                     flat = flat_model.gather()
                     if count_sums is None:
                         count_sums = machine.expected_count_sums()

@@ -41,7 +41,7 @@ class EmOptimizer(IOptimizer):
                 ll = machine.log_likelihood()
             if hasattr(machine, "expected_count_sums"):
                 if flat_model is None:
-                    flat_model = FlatModel(self._network)
+                    flat_model = FlatModel.of(self._network)
                 if count_sums is None:
                     count_sums = machine.expected_count_sums()
                 sums, ll, _ = reduce_statistics(machine, count_sums, ll, self._settings.sharded)

@@ -80,19 +80,48 @@ class FlatModel:
         self.device, self.dtype = first.device, first.dtype
         self.shapes = [tuple(n.cpt.shape) for n in self.nodes]
         self.sizes = [n.cpt.numel() for n in self.nodes]
-        rows, inv = [], []
-        row_base = 0
-        for shape, size in zip(self.shapes, self.sizes):
-            s_last = shape[-1]
-            n_rows = size // s_last
-            rows.append(torch.arange(row_base, row_base + n_rows).repeat_interleave(s_last))
-            inv.append(torch.full((size,), 1.0 / s_last, dtype=torch.float64))
-            row_base += n_rows
-        self.num_rows = row_base
-        self.row_ids = torch.cat(rows).to(self.device)
-        self.inv_states = torch.cat(inv).to(self.device)
         self._network = network
         self._store = None
+        self._index = None  # (num_rows, row_ids, inv_states), built when the tensor M-step is first used
+
+    @classmethod
+    def of(cls, network: BayesianNetwork) -> "FlatModel":
+        """The network's flat model, kept on the network between optimizer runs (building it walks
+        every node; a second ``optimize`` call on the same network finds it ready)."""
+        model = network.__dict__.get("_flat_model")
+        if model is not None:
+            cpts = [n.cpt for n in network.nodes]
+            if (model.shapes != [tuple(c.shape) for c in cpts] or cpts[0].device != model.device
+                    or cpts[0].dtype != model.dtype):
+                model = None
+        if model is None:
+            model = network.__dict__["_flat_model"] = cls(network)
+        return model
+
+    def _row_index(self):
+        if self._index is None:
+            rows, inv = [], []
+            row_base = 0
+            for shape, size in zip(self.shapes, self.sizes):
+                s_last = shape[-1]
+                n_rows = size // s_last
+                rows.append(torch.arange(row_base, row_base + n_rows).repeat_interleave(s_last))
+                inv.append(torch.full((size,), 1.0 / s_last, dtype=torch.float64))
+                row_base += n_rows
+            self._index = (row_base, torch.cat(rows).to(self.device), torch.cat(inv).to(self.device))
+        return self._index
+
+    @property
+    def num_rows(self):
+        return self._row_index()[0]
+
+    @property
+    def row_ids(self):
+        return self._row_index()[1]
+
+    @property
+    def inv_states(self):
+        return self._row_index()[2]
 
     def views(self, flat: torch.Tensor) -> List[torch.Tensor]:
         out, pos = [], 0

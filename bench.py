@@ -169,8 +169,8 @@ def cpu_baseline(model: str, n: int, steps: int, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="observations per GPU per step")
     ap.add_argument("--model", choices=["c3a", "c3b", "c5"], default="c3a")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
