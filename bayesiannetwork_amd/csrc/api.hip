@@ -414,6 +414,7 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
   }
 
   auto bail = [&](int rc) {
+    bn::release_fast(p);
     release(p);
     delete h;
     return rc;
@@ -519,7 +520,7 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     }
     BN_TRY_HIP(hipGetLastError());
   }
-  BN_TRY(bn::prepare_fast(p));
+  if (bn::prepare_fast(p) != 0) return bail(fail(BN_ERR_HIP, "device allocation for the specialised kernels failed"));
   BN_TRY(p.dtype == BN_F32 ? reset_messages_t<float>(p, nullptr) : reset_messages_t<double>(p, nullptr));
   BN_TRY_HIP(hipStreamSynchronize(nullptr));
 #undef BN_TRY

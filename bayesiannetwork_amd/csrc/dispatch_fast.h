@@ -42,6 +42,8 @@ struct WideNode {
 
 struct FusedFamily {
   int32_t wide_index = -1;
+  int32_t wide_index2 = -1;     // second wide parent of two-parent families, else -1
+  float* m_state = nullptr;     // [K][D0 + D1][npad] two-parent loop state (previous messages to the parents)
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
   float* z_state = nullptr;     // [K][npad] loop-state normalisers
@@ -70,15 +72,8 @@ struct FastState {
   std::vector<char> root_written;
 };
 
-inline std::map<const Plan*, FastState>& fast_states() {
-  static std::map<const Plan*, FastState> states;
-  return states;
-}
-
-inline FastState* fast_state(const Plan& p) {
-  auto it = fast_states().find(&p);
-  return it == fast_states().end() ? nullptr : &it->second;
-}
+// The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
+inline FastState* fast_state(const Plan& p) { return static_cast<FastState*>(p.fast); }
 
 inline bool small_dim(int32_t d) {
   switch (d) {
@@ -122,9 +117,11 @@ inline void release_fast(Plan& p) {
     if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
     if (kv.second.z_state) (void)hipFree(kv.second.z_state);
     if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
+    if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
   if (st->d_ll_offs) (void)hipFree(st->d_ll_offs);
-  fast_states().erase(&p);
+  delete st;
+  p.fast = nullptr;
 }
 
 inline void invalidate_fast(Plan& p) {
@@ -143,13 +140,12 @@ inline void cpts_changed_fast(Plan& p) {
 }
 
 inline int prepare_fast(Plan& p) {
-  FastState st;
+  // built in place, so that release_fast frees whatever a failed preparation had allocated
+  p.fast = new FastState;
+  FastState& st = *fast_state(p);
   st.vgroup_skip.assign(p.vgroups.size(), 0);
   st.root_written.assign(p.fgroups.size(), 0);
-  if (p.dtype != 0) {
-    fast_states()[&p] = std::move(st);
-    return 0;
-  }
+  if (p.dtype != 0) return 0;
   // wide variable nodes
   for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
     const VariableGroup& g = p.vgroups[gi];
@@ -165,32 +161,45 @@ inline int prepare_fast(Plan& p) {
       st.wide.push_back(std::move(w));
     }
   }
-  // leaf families around a wide parent
+  // leaf families around one or two wide parents
   std::vector<char> handled(p.n_nodes, 0);
   for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
     const FactorGroup& g = p.fgroups[fi];
-    if (g.dims.size() != 2 || !small_dim(g.dims[0]) || !small_dim(g.dims[1])) continue;
-    const int32_t parent = p.parents[g.nodes[0]][0];
-    auto wit = st.wide_of_node.find(parent);
-    if (wit == st.wide_of_node.end()) continue;
-    WideNode& w = st.wide[wit->second];
-    if (w.fused_fgroup >= 0) continue;
-    bool ok = g.nodes.size() >= 16;
-    for (int32_t j : g.nodes) ok = ok && p.parents[j][0] == parent && p.children[j].empty();
-    if (!ok || w.I - (int32_t)g.nodes.size() > kMaxUncovered) continue;
-    // covered slots of the parent, in the factor group's node order
-    std::vector<char> is_covered(w.I, 0);
-    for (int32_t j : g.nodes) {
-      const auto& ch = p.children[parent];
-      const int32_t slot = (int32_t)(std::find(ch.begin(), ch.end(), j) - ch.begin());
-      w.covered.push_back(slot);
-      is_covered[slot] = 1;
+    const int32_t num_parents = (int32_t)g.dims.size() - 1;
+    if (num_parents == 2) {
+      if (g.dims[0] != 2 || g.dims[1] != 2 || g.dims[2] != 2) continue;  // the instantiated two-parent shape
+    } else if (num_parents != 1 || !small_dim(g.dims[0]) || !small_dim(g.dims[1])) {
+      continue;
     }
-    for (int32_t i = 0; i < w.I; ++i)
-      if (!is_covered[i]) w.uncovered.push_back(i);
-    w.fused_fgroup = (int32_t)fi;
-    FusedFamily fam;
-    fam.wide_index = wit->second;
+    const std::vector<int32_t>& family_parents = p.parents[g.nodes[0]];
+    int32_t widx[2] = {-1, -1};
+    bool ok = g.nodes.size() >= 16;
+    for (int32_t q = 0; q < num_parents && ok; ++q) {
+      auto wit = st.wide_of_node.find(family_parents[q]);
+      ok = wit != st.wide_of_node.end() && st.wide[wit->second].fused_fgroup < 0 &&
+           st.wide[wit->second].I - (int32_t)g.nodes.size() <= kMaxUncovered;
+      if (ok) widx[q] = wit->second;
+    }
+    ok = ok && (num_parents == 1 || widx[0] != widx[1]);
+    for (int32_t j : g.nodes) ok = ok && p.parents[j] == family_parents && p.children[j].empty();
+    if (!ok) continue;
+    // covered slots of each parent, in the factor group's node order
+    for (int32_t q = 0; q < num_parents; ++q) {
+      WideNode& w = st.wide[widx[q]];
+      std::vector<char> is_covered(w.I, 0);
+      const auto& ch = p.children[family_parents[q]];
+      for (int32_t j : g.nodes) {
+        const int32_t slot = (int32_t)(std::find(ch.begin(), ch.end(), j) - ch.begin());
+        w.covered.push_back(slot);
+        is_covered[slot] = 1;
+      }
+      for (int32_t i = 0; i < w.I; ++i)
+        if (!is_covered[i]) w.uncovered.push_back(i);
+      w.fused_fgroup = (int32_t)fi;
+    }
+    FusedFamily& fam = st.fused[(int32_t)fi];  // in place: release_fast frees it whatever happens below
+    fam.wide_index = widx[0];
+    fam.wide_index2 = widx[1];
     std::vector<int64_t> obs, cs;
     for (int32_t j : g.nodes) {
       obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : p.ones_off);
@@ -205,7 +214,11 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&fam.z_state), g.nodes.size() * (size_t)p.npad * sizeof(float)) != hipSuccess)
       return -2;
     p.device_bytes += (int64_t)(g.nodes.size() * (size_t)p.npad * sizeof(float));
-    st.fused[(int32_t)fi] = fam;
+    if (num_parents == 2) {
+      const size_t m_elems = g.nodes.size() * (size_t)(g.dims[0] + g.dims[1]) * p.npad;
+      if (hipMalloc(reinterpret_cast<void**>(&fam.m_state), m_elems * sizeof(float)) != hipSuccess) return -2;
+      p.device_bytes += (int64_t)(m_elems * sizeof(float));
+    }
   }
   for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
     bool all = true;
@@ -243,7 +256,7 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), rows * sizeof(int32_t)) != hipSuccess) return -2;
     if (hipMalloc(reinterpret_cast<void**>(&w.scaled), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
     p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 8);
-    if (w.fused_fgroup >= 0) {
+    if (w.fused_fgroup >= 0 && !st.fused[w.fused_fgroup].ll_part) {
       FusedFamily& fam = st.fused[w.fused_fgroup];
       fam.ll_rows = w.chunks;
       if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)w.chunks * p.npad * sizeof(double)) != hipSuccess)
@@ -251,7 +264,6 @@ inline int prepare_fast(Plan& p) {
       p.device_bytes += (int64_t)((size_t)w.chunks * p.npad * sizeof(double));
     }
   }
-  fast_states()[&p] = std::move(st);
   return 0;
 }
 
@@ -435,19 +447,21 @@ inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
   return nullptr;
 }
 
-inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, float* arena, const float* cpts,
-                              int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s) {
+// w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
+inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, float* arena,
+                              const float* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s) {
   const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
   LeafFamilyFn fn = nullptr;
   switch (mode + 3 * state) {
-#define X(M)                                              \
-  case M:                                                 \
-    fn = leaf_family_lookup<M>(g.dims[0], g.dims[1]);     \
+#define X(M)                                                                                        \
+  case M:                                                                                           \
+    fn = w2 ? leaf_family_p2<2, 2, 2, kLeafVec, M> : leaf_family_lookup<M>(g.dims[0], g.dims[1]);   \
     break;
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
   }
   if (!fn) return -1;
+  if (w2 && (w2->chunks != w.chunks || w2->chunk_len != w.chunk_len)) return -1;
   LeafFamilyArgs a;
   a.f_in = g.d_in;
   a.f_out = g.d_out;
@@ -469,6 +483,10 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.em_partial = fam.em_partial;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
+  a.part_mant2 = w2 ? w2->part_mant : nullptr;
+  a.part_exp2 = w2 ? w2->part_exp : nullptr;
+  a.scaled2 = w2 ? w2->scaled : nullptr;
+  a.m_state = fam.m_state;
   launch(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
@@ -480,6 +498,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     fam.pending = false;
     fam.em_ready = false;
     w.partials_valid = true;
+    if (w2) w2->partials_valid = true;
   }
   return 1;
 }
@@ -493,7 +512,8 @@ inline int complete_pending_fast(Plan& p, hipStream_t s) {
     FusedFamily& fam = kv.second;
     if (!fam.pending) continue;
     FactorGroup& g = p.fgroups[kv.first];
-    int rc = launch_leaf_family(p, g, fam, st->wide[fam.wide_index], static_cast<float*>(p.arena),
+    int rc = launch_leaf_family(p, g, fam, st->wide[fam.wide_index],
+                                fam.wide_index2 >= 0 ? &st->wide[fam.wide_index2] : nullptr, static_cast<float*>(p.arena),
                                 static_cast<const float*>(p.cpts), fam.pending_fresh, fam.pending_first, kLeafFull, s);
     if (rc < 0) return rc;
   }
@@ -564,7 +584,8 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       if (it != st->fused.end()) {
         WideNode& w = st->wide[it->second.wide_index];
         const int32_t mode = !last_iteration ? kLeafLoop : (reduce_last ? kLeafReduce : kLeafFull);
-        return launch_leaf_family(p, g, it->second, w, arena, cpts, fresh, first_iteration, mode, s);
+        WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
+        return launch_leaf_family(p, g, it->second, w, w2, arena, cpts, fresh, first_iteration, mode, s);
       }
     }
     if (g.dims.size() == 1) {

@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena,
 // ---------------------------------------------------------------------------------
 // Leaf families with one (wide) parent: see the file header.
 struct LeafFamilyArgs {
-  const int64_t* f_in;     // [K*2]  v2f offsets of the factor group (parent slot, own slot)
-  const int64_t* f_out;    // [K*2]  f2v offsets
+  const int64_t* f_in;     // [K*arity]  v2f offsets of the factor group (parent slots, own slot)
+  const int64_t* f_out;    // [K*arity]  f2v offsets
   const int64_t* cpt_off;  // [K]
   const int64_t* obs_off;  // [K]    observation array of the own variable, -1 = not observed
   const int64_t* c_off;    // [K]    normaliser of the own variable
@@ -311,6 +311,12 @@ struct LeafFamilyArgs {
   float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable)
   int32_t slots;      // ntiles * waves per tile
   double* ll_part;    // [chunks][npad] sum over the chunk's families of c = log z, per observation
+  // two-parent families (leaf_family_p2) only: the second wide parent's partial products and P',
+  // and the loop state that holds the factor's previous messages to both parents
+  double* part_mant2;
+  int32_t* part_exp2;
+  const double* scaled2;
+  float* m_state;  // [K][D0 + D1][npad]
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
@@ -673,6 +679,256 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       a.part_exp[row] = ex[0];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Leaf families with TWO wide parents (CPT [D0][D1][S], e.g. the loopy 784-leaf model's
+// Y | F1, F2).  Same structure as leaf_family_p1; differences:
+//   * the factor's previous messages to the parents depend on the other parent's message, so they
+//     cannot be rebuilt from the evidence: the loop state is m1[D0], m2[D1] and the leaf's next z;
+//   * the kernel maintains the chunk partial products of both parents.
+// Per family and observation the loop moves D0+D1+1+S floats in and D0+D1+1 out (7 + 5 for the
+// (2,2,2) families) instead of the 36 of the unfused passes.
+template <int N, int V>
+__device__ __forceinline__ void load_scaled(const double* __restrict__ scaled, int64_t npad, fv<V>* out) {
+#pragma unroll
+  for (int32_t i = 0; i < N; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) out[i][v] = (float)scaled[(int64_t)i * npad + v];
+}
+
+template <int N, int V>
+__device__ __forceinline__ void store_partials(double* __restrict__ mant, int32_t* __restrict__ exps, int64_t base,
+                                               int64_t npad, double (&pm)[N][V], const ev_t<V>* pe) {
+#pragma unroll
+  for (int32_t s = 0; s < N; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      mant[base + (int64_t)s * npad + v] = frexp(pm[s][v], &de);
+      exps[base + (int64_t)s * npad + v] = (int32_t)pe[s][v] + de;
+    }
+}
+
+template <int D0, int D1, int S, int V, int MODE>
+__global__ void __launch_bounds__(256) leaf_family_p2(float* __restrict__ arena, const float* __restrict__ cpts,
+                                                     LeafFamilyArgs a) {
+  constexpr bool FULL = MODE % 3 == kLeafFull;
+  constexpr bool REDUCE = MODE % 3 == kLeafReduce;
+  constexpr int32_t STATE = MODE / 3;
+  constexpr int32_t kParts = 4 / V;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
+  const int32_t part = (int32_t)(w % kParts);
+  w /= kParts;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+  const int32_t col = part * 64 * V + lane * V;
+  const int32_t first = chunk * a.chunk_len;
+  const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
+  if (first >= last) return;
+
+  double pm1[D0][V], pm2[D1][V];
+  ev_t<V> pe1[D0], pe2[D1];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) {
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) {
+      pm1[i][v] = 1.0;
+      pe1[i][v] = 0;
+    }
+#pragma unroll
+    for (int32_t i = 0; i < D1; ++i) {
+      pm2[i][v] = 1.0;
+      pe2[i][v] = 0;
+    }
+  }
+  fv<V> pf1[D0], pf2[D1];
+  load_scaled<D0, V>(a.scaled + t * kTile + col, a.npad, pf1);
+  load_scaled<D1, V>(a.scaled2 + t * kTile + col, a.npad, pf2);
+
+  double ll_acc[V];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) ll_acc[v] = 0.0;
+
+  for (int32_t k = first; k < last; ++k) {
+    const float* cpt = cpts + a.cpt_off[k];
+    float* f2v_p1 = arena + a.f_out[3 * k];
+    float* f2v_p2 = arena + a.f_out[3 * k + 1];
+    float* f2v_own = arena + a.f_out[3 * k + 2];
+    float* m_state = a.m_state + (int64_t)k * (D0 + D1) * a.npad;
+    float* z_state = a.z_state + (int64_t)k * a.npad;
+    const float* obs = arena + a.obs_off[k];
+
+    fv<V> ev[S], prev1[D0], prev2[D1], z;
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) ev[j] = loadv<V>(obs, t * S + j, col);
+    if constexpr (STATE == kLeafSteady) {
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) prev1[i] = loadv<V>(m_state, t * (D0 + D1) + i, col);
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) prev2[i] = loadv<V>(m_state, t * (D0 + D1) + D0 + i, col);
+      z = loadv<V>(z_state, t, col);
+    } else {
+      fv<V> own[S];
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+        prev1[i] = STATE == kLeafFresh ? splat<V>(1.0f / (float)D0) : loadv<V>(f2v_p1, t * D0 + i, col);
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i)
+        prev2[i] = STATE == kLeafFresh ? splat<V>(1.0f / (float)D1) : loadv<V>(f2v_p2, t * D1 + i, col);
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+        own[j] = STATE == kLeafFresh ? splat<V>(1.0f / (float)S) : loadv<V>(f2v_own, t * S + j, col);
+      z = leaf_normaliser<S, V>(ev, own);
+    }
+
+    // both parents' messages to this factor: (P'/previous message) normalised over the states
+    fv<V> t1[D0], t2[D1];
+    {
+      fv<V> sum = splat<V>(0.f);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        t1[i] = pf1[i] * rcpv<V>(prev1[i]);
+        sum += t1[i];
+      }
+      sum = rcpv<V>(sum);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) t1[i] *= sum;
+      sum = splat<V>(0.f);
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) {
+        t2[i] = pf2[i] * rcpv<V>(prev2[i]);
+        sum += t2[i];
+      }
+      sum = rcpv<V>(sum);
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) t2[i] *= sum;
+    }
+    // the leaf's variable pass: c = log z, message to the factor = ev / z
+    const fv<V> inv_z = recipv<V>(z);
+    fv<V> o[S];
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) o[j] = ev[j] * inv_z;
+    if (FULL || REDUCE) {
+      fv<V> c;
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        int de = 0;
+        const float mz = frexpf(z[v], &de);
+        c[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
+        if (REDUCE) ll_acc[v] += (double)c[v];
+      }
+      if (FULL) storev<V>(arena + a.c_off[k], t, col, c);
+    }
+    if constexpr (REDUCE) {
+      // EM counts over the wave's observations (padding masked), wave-reduced
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v)
+          if (t * kTile + col + v >= a.N) o[j][v] = 0.f;
+      float* dst = a.em_partial + ((int64_t)k * (D0 * D1 * S)) * a.slots + (t * kParts + part);
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+        for (int32_t l = 0; l < D1; ++l) {
+          const fv<V> tt = t1[i] * t2[l];
+#pragma unroll
+          for (int32_t j = 0; j < S; ++j) {
+            const fv<V> prod = tt * o[j];
+            float x = prod[0];
+#pragma unroll
+            for (int32_t v = 1; v < V; ++v) x += prod[v];
+            x = wave_sum_lane63(x);
+            if (lane == 63) dst[(int64_t)((i * D1 + l) * S + j) * a.slots] = x;
+          }
+        }
+      continue;
+    }
+    // contractions: A[i][l] = sum_j cpt[i][l][j] o[j];  m1 = A t2;  m2 = A^T t1;  own = cpt^T (t1 x t2)
+    fv<V> m1[D0], m2[D1], own[S];
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) m1[i] = splat<V>(0.f);
+#pragma unroll
+    for (int32_t l = 0; l < D1; ++l) m2[l] = splat<V>(0.f);
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) own[j] = splat<V>(0.f);
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+      for (int32_t l = 0; l < D1; ++l) {
+        const float* row = cpt + (i * D1 + l) * S;
+        fv<V> A = row[0] * o[0];
+#pragma unroll
+        for (int32_t j = 1; j < S; ++j) A = __builtin_elementwise_fma(splat<V>(row[j]), o[j], A);
+        m1[i] = __builtin_elementwise_fma(A, t2[l], m1[i]);
+        m2[l] = __builtin_elementwise_fma(A, t1[i], m2[l]);
+        const fv<V> tt = t1[i] * t2[l];
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) own[j] = __builtin_elementwise_fma(splat<V>(row[j]), tt, own[j]);
+      }
+    if (FULL) {
+      float* v2f_p1 = arena + a.f_in[3 * k];
+      float* v2f_p2 = arena + a.f_in[3 * k + 1];
+      float* v2f_own = arena + a.f_in[3 * k + 2];
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        storev<V>(v2f_p1, t * D0 + i, col, t1[i]);
+        storev<V>(f2v_p1, t * D0 + i, col, m1[i]);
+      }
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) {
+        storev<V>(v2f_p2, t * D1 + i, col, t2[i]);
+        storev<V>(f2v_p2, t * D1 + i, col, m2[i]);
+      }
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) {
+        storev<V>(v2f_own, t * S + j, col, o[j]);
+        storev<V>(f2v_own, t * S + j, col, own[j]);
+      }
+    } else {
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) storev<V>(m_state, t * (D0 + D1) + i, col, m1[i]);
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) storev<V>(m_state, t * (D0 + D1) + D0 + i, col, m2[i]);
+      storev<V>(z_state, t, col, leaf_normaliser<S, V>(ev, own));
+    }
+    // fold into both parents' partial products
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) pm1[i][v] *= (double)m1[i][v];
+#pragma unroll
+      for (int32_t i = 0; i < D1; ++i) pm2[i][v] *= (double)m2[i][v];
+    }
+    if (((k - first) & 3) == 3) {
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+#pragma unroll
+        for (int32_t i = 0; i < D0; ++i) {
+          int de = 0;
+          pm1[i][v] = frexp(pm1[i][v], &de);
+          pe1[i][v] += de;
+        }
+#pragma unroll
+        for (int32_t i = 0; i < D1; ++i) {
+          int de = 0;
+          pm2[i][v] = frexp(pm2[i][v], &de);
+          pe2[i][v] += de;
+        }
+      }
+    }
+  }
+  if constexpr (REDUCE) {
+    double* dst = a.ll_part + (int64_t)chunk * a.npad + t * kTile + col;
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) dst[v] = ll_acc[v];
+    return;
+  }
+  store_partials<D0, V>(a.part_mant, a.part_exp, (int64_t)chunk * D0 * a.npad + t * kTile + col, a.npad, pm1, pe1);
+  store_partials<D1, V>(a.part_mant2, a.part_exp2, (int64_t)chunk * D1 * a.npad + t * kTile + col, a.npad, pm2, pe2);
 }
 
 // accum[entry] = cpt[entry] * sum over the per-wave sums written by the kLeafReduce kernel.

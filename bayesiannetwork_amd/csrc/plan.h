@@ -94,6 +94,7 @@ struct Plan {
   void* cpts = nullptr;        // flat CPT snapshot
   double* scratch = nullptr;   // reduction partials
   int64_t scratch_elems = 0;
+  void* fast = nullptr;  // state of the specialised float32 kernels (dispatch_fast.h), owned by the plan
   void** d_evidence_ptrs = nullptr;  // device array of evidence source addresses
   // pinned staging for the above: a ring of kStagingSlots tables, each guarded by an event that
   // marks when its last upload has left it, so that bn_enter_evidence never waits for the device
