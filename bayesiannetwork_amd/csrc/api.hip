@@ -749,14 +749,16 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream) {
 
 int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
                      void* stream) {
-  if (!plan || !ll_out_dev || !accum_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
   if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
   bn::Plan& p = plan->p;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_observations(p, s)) return rc;
-  int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 1, s) : iterate_t<double>(p, num_iterations, 1, s);
+  const int32_t reduce_last = accum_dev ? 1 : 2;
+  int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, reduce_last, s)
+                             : iterate_t<double>(p, num_iterations, reduce_last, s);
   if (rc != BN_OK) return rc;
   {
     // the fused families left their normalisers as per-observation partial sums
@@ -773,7 +775,7 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
       rc = bn_log_likelihood(plan, average, ll_out_dev, stream);
     }
   }
-  if (rc != BN_OK) return rc;
+  if (rc != BN_OK || !accum_dev) return rc;
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
 }
 

@@ -449,7 +449,8 @@ inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
 
 // w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
 inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, float* arena,
-                              const float* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s) {
+                              const float* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
+                              bool with_counts = true) {
   const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
   LeafFamilyFn fn = nullptr;
   switch (mode + 3 * state) {
@@ -480,7 +481,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.prev_from_arrays = first_iteration;
   a.N = p.N;
   a.z_state = fam.z_state;
-  a.em_partial = fam.em_partial;
+  a.em_partial = with_counts ? fam.em_partial : nullptr;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
   a.part_mant2 = w2 ? w2->part_mant : nullptr;
@@ -493,7 +494,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     fam.pending = true;
     fam.pending_fresh = fresh;
     fam.pending_first = first_iteration;
-    fam.em_ready = true;
+    fam.em_ready = with_counts;
   } else {
     fam.pending = false;
     fam.em_ready = false;
@@ -585,7 +586,9 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
         WideNode& w = st->wide[it->second.wide_index];
         const int32_t mode = !last_iteration ? kLeafLoop : (reduce_last ? kLeafReduce : kLeafFull);
         WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
-        return launch_leaf_family(p, g, it->second, w, w2, arena, cpts, fresh, first_iteration, mode, s);
+        // reduce_last == 2: only the log-likelihood sums are wanted from the reduce-mode launch
+        return launch_leaf_family(p, g, it->second, w, w2, arena, cpts, fresh, first_iteration, mode, s,
+                                  reduce_last != 2);
       }
     }
     if (g.dims.size() == 1) {

@@ -308,7 +308,7 @@ struct LeafFamilyArgs {
   float* z_state;  // [K][npad] loop state: the leaf's normaliser z for the coming iteration
   // kLeafReduce only
   int64_t N;
-  float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable)
+  float* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable); nullptr = not wanted
   int32_t slots;      // ntiles * waves per tile
   double* ll_part;    // [chunks][npad] sum over the chunk's families of c = log z, per observation
   // two-parent families (leaf_family_p2) only: the second wide parent's partial products and P',
@@ -585,6 +585,11 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) r[i] *= inv_sum;  // now the normalised message
       if constexpr (REDUCE) {
+        if (!a.em_partial) {  // only the log-likelihood sums are wanted
+          ptr = ptr_next;
+          cur = nxt;
+          continue;
+        }
         // EM counts of this family over the wave's observations (padding masked), wave-reduced
 #pragma unroll
         for (int32_t j = 0; j < S; ++j)
@@ -823,6 +828,7 @@ __global__ void __launch_bounds__(256) leaf_family_p2(float* __restrict__ arena,
       if (FULL) storev<V>(arena + a.c_off[k], t, col, c);
     }
     if constexpr (REDUCE) {
+      if (!a.em_partial) continue;  // only the log-likelihood sums are wanted
       // EM counts over the wave's observations (padding masked), wave-reduced
 #pragma unroll
       for (int32_t j = 0; j < S; ++j)

@@ -329,9 +329,20 @@ class HipSpaInferenceMachine(IInferenceMachine):
     # ------------------------------------------------------------------ extensions
     def log_likelihood_tensor(self) -> torch.Tensor:
         """Log-likelihood as a one-element float64 device tensor (no host sync)."""
+        out = torch.empty((1,), device=self._device, dtype=torch.float64)
+        if self.must_iterate and not self._settings.callback:
+            # iterations and log-likelihood in one engine call; the last iteration's messages are
+            # completed by the engine if a later query needs them
+            with torch.cuda.device(self._device):
+                _native.check(
+                    self._lib.bn_em_statistics(self._plan, self._num_iterations,
+                                               1 if self._settings.average_log_likelihood else 0,
+                                               ctypes.c_void_p(out.data_ptr()), None, self._stream())
+                )
+            self.must_iterate = False
+            return out
         if self.must_iterate:
             self._iterate()
-        out = torch.empty((1,), device=self._device, dtype=torch.float64)
         with torch.cuda.device(self._device):
             _native.check(
                 self._lib.bn_log_likelihood(self._plan, 1 if self._settings.average_log_likelihood else 0,

@@ -157,6 +157,9 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream);
  * Equivalent to bn_iterate + bn_log_likelihood + bn_em_accumulate, but the last iteration may
  * be evaluated on the fly for the statistics without storing its messages; they are brought up
  * to date automatically by the next call that reads or changes messages, evidence or CPTs.
+ * accum_dev may be NULL: then only the log-likelihood is produced (inference without an
+ * E-step: SpaInferenceMachine.log_likelihood on a machine that has not iterated yet,
+ * spa_v3/spa_inference_machine.py:121-137).
  * Replaces the body of EmBatchOptimizer.optimize's step up to the M-step
  * (optimizers/em_batch_optimizer.py:44-48: enter_evidence excluded).
  */

@@ -142,8 +142,18 @@ def test_em_statistics_equals_separate_calls_and_leaves_queries_intact(name):
     ev = Evidence(fx.evidence_tensors("cuda"), ts)
     plain = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
     plain.enter_evidence(ev)
+    plain._iterate()  # bn_iterate: every message of the last iteration stored
     ll_plain = plain.log_likelihood_tensor()
     counts_plain = plain.expected_count_sums()
+
+    # log-likelihood asked first: iterations + ll in one call, nothing of the last iteration stored
+    ll_only = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
+    ll_only.enter_evidence(ev)
+    np.testing.assert_allclose(ll_only.log_likelihood_tensor().item(), ll_plain.item(), rtol=1e-7)
+    np.testing.assert_allclose(ll_only.expected_count_sums().cpu().numpy(), counts_plain.cpu().numpy(), rtol=2e-6,
+                               atol=1e-12)
+    for a, b in zip(ll_only.infer_single_nodes(list(network.nodes)), plain.infer_single_nodes(list(network.nodes))):
+        assert torch.equal(a, b)
 
     fused = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
     fused.enter_evidence(ev)
@@ -162,6 +172,7 @@ def test_em_statistics_equals_separate_calls_and_leaves_queries_intact(name):
     # and the state keeps evolving identically: a second round of evidence on both
     ev2 = Evidence([torch.flip(e, dims=[0]).contiguous() for e in fx.evidence_tensors("cuda")], ts)
     plain.enter_evidence(ev2)
+    plain._iterate()
     fused.enter_evidence(ev2)
     l2, c2 = fused.em_statistics()
     np.testing.assert_allclose(l2.item(), plain.log_likelihood_tensor().item(), rtol=1e-7)
