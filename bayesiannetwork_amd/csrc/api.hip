@@ -171,9 +171,6 @@ void release(bn::Plan& p) {
   if (p.cpts) (void)hipFree(p.cpts);
   if (p.scratch) (void)hipFree(p.scratch);
   if (p.d_evidence_ptrs) (void)hipFree(p.d_evidence_ptrs);
-  if (p.h_evidence_ptrs) (void)hipHostFree(p.h_evidence_ptrs);
-  for (void* e : p.staging_events)
-    if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   if (p.d_obs_off) (void)hipFree(p.d_obs_off);
   if (p.d_obs_states) (void)hipFree(p.d_obs_states);
   if (p.d_fill_off) (void)hipFree(p.d_fill_off);
@@ -461,13 +458,6 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY(upload(p.obs_off, &p.d_obs_off, p.device_bytes));
     BN_TRY(upload(obs_states, &p.d_obs_states, p.device_bytes));
     BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_evidence_ptrs), p.observed.size() * sizeof(void*)));
-    BN_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&p.h_evidence_ptrs),
-                             bn::Plan::kStagingSlots * p.observed.size() * sizeof(void*), hipHostMallocDefault));
-    for (void*& e : p.staging_events) {
-      hipEvent_t ev;
-      BN_TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      e = ev;
-    }
     p.obs_all_pairs = p.dtype == BN_F32 && p.tile % 2 == 0;
     for (int32_t st : obs_states) p.obs_all_pairs = p.obs_all_pairs && st == 2;
   }
@@ -586,18 +576,16 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   // same sources as last time: the device table is already right
   const bool same_table = p.evidence_on_device.size() == count &&
                           std::memcmp(p.evidence_on_device.data(), evidence_dev, count * sizeof(void*)) == 0;
-  // next slot of the pinned staging ring; wait only if its previous upload is still in flight
   if (!same_table) {
-  const int32_t slot = p.staging_next;
-  p.staging_next = (slot + 1) % bn::Plan::kStagingSlots;
-  hipEvent_t slot_event = static_cast<hipEvent_t>(p.staging_events[slot]);
-  if (p.staging_used[slot]) BN_HIP_CHECK(hipEventSynchronize(slot_event));
-  void** staging = p.h_evidence_ptrs + (size_t)slot * count;
-  std::memcpy(staging, evidence_dev, count * sizeof(void*));
-  BN_HIP_CHECK(hipMemcpyAsync(p.d_evidence_ptrs, staging, count * sizeof(void*), hipMemcpyHostToDevice, s));
-  BN_HIP_CHECK(hipEventRecord(slot_event, s));
-  p.staging_used[slot] = true;
-  p.evidence_on_device.assign(evidence_dev, evidence_dev + count);
+    for (size_t first = 0; first < count; first += bn::kAddressBatch) {
+      const int32_t cnt = (int32_t)std::min<size_t>(count - first, bn::kAddressBatch);
+      bn::AddressBatch batch;
+      std::memcpy(batch.p, evidence_dev + first, (size_t)cnt * sizeof(void*));
+      bn::launch(bn::store_addresses, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, batch, cnt,
+                 const_cast<const void**>(p.d_evidence_ptrs) + first);
+      BN_LAUNCH_CHECK("store_addresses");
+    }
+    p.evidence_on_device.assign(evidence_dev, evidence_dev + count);
   }
   const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
   {

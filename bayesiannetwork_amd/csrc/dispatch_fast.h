@@ -243,6 +243,9 @@ inline int prepare_fast(Plan& p) {
     // second one: measured best on the 784-leaf model (8 chunks at 60 000 observations; 7 and 9
     // are both 5 % slower, 13 and more pay in the combine)
     int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * (4 / kLeafVec)));
+    // small batches cannot fill the chip anyway; there the combine sets the limit: its waves
+    // each walk a share of the chunks, three groups of four at most
+    want = std::min<int64_t>(want, 4 * kCombineMaxWaves * 3);
     if (getenv("BN_WIDE_CHUNKS")) want = atoi(getenv("BN_WIDE_CHUNKS"));
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
     // the leaf-family kernel keeps a chunk's exponents in 16 bits
@@ -304,7 +307,12 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
     launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
     if (!launch_ok()) return false;
   }
-  launch(wide_combine_fast<S>, dim3(wave_blocks(p.ntiles * (kTile / 64))), dim3(256), 0, s, arena, a);
+  {
+    // waves per block: one per group of four chunks, none to spare while the messages are fresh
+    const int32_t nw = fresh ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
+    launch(wide_combine_fast<S>, dim3((uint32_t)(p.ntiles * (kTile / 64))), dim3(64 * nw), combine_lds_bytes<S>(nw), s,
+           arena, a);
+  }
   if (!launch_ok()) return false;
   if (!fused) {
     launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);

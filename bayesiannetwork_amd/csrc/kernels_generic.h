@@ -261,6 +261,18 @@ __global__ void __launch_bounds__(256) evidence_scatter(T* __restrict__ arena,
   arena[obs_off[o] + idx] = n < N ? src[n * S + s] : (T)1;
 }
 
+// Writes a batch of addresses, handed over as kernel arguments, into a device table.  Kernel
+// arguments are captured at launch, so the caller's table needs no staging buffer and the upload is
+// ordered with the stream without any host-side wait.
+constexpr int32_t kAddressBatch = 448;  // 3.5 KiB of the 4 KiB kernel-argument space
+struct AddressBatch {
+  const void* p[kAddressBatch];
+};
+__global__ void __launch_bounds__(256) store_addresses(AddressBatch batch, int32_t count, const void** __restrict__ dst) {
+  const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (i < count) dst[i] = batch.p[i];
+}
+
 // Two-state float evidence, two observations per lane: 16 bytes in ([e0 e1 | e0 e1]), 8 bytes out
 // to each of the two state rows.  Sources that are not 16-byte aligned are read element-wise.
 // grid = (ceil(npad / 512), num_observed); tile must be even

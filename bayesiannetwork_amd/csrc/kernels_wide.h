@@ -127,27 +127,37 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
   store_partial<S>(a, chunk, t, lane, m, e);
 }
 
-// One observation per lane, four waves per tile: the launch is short and latency-bound, so it
-// wants as many waves as it can get, and the partials of four chunks are requested together.
+// One observation per lane; a block owns 64 observations and its waves share the chunks: wave w
+// multiplies the partials of chunks 4w..4w+3, 4(w+nw).., requested four chunks at a time, hands its
+// product to wave 0 through LDS, and wave 0 finishes.  The launch is short and latency-bound, so
+// it wants the chunk walk as parallel as it can get.
+//   grid.x = ntiles * 4, block = 64 * nw (nw <= kCombineMaxWaves), dynamic LDS = combine_lds_bytes<S>(nw)
+constexpr int32_t kCombineMaxWaves = 8;
 template <int S>
-__global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
+constexpr size_t combine_lds_bytes(int32_t nw) {
+  return nw > 1 ? (size_t)nw * S * 64 * (sizeof(double) + sizeof(int32_t)) : 0;
+}
+
+template <int S>
+__global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(float* __restrict__ arena, WideArgs a) {
+  extern __shared__ __align__(16) unsigned char combine_lds[];
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (w >= a.ntiles * (kTile / 64)) return;
-  const int64_t t = w / (kTile / 64);
-  const int32_t col = (int32_t)(w % (kTile / 64)) * 64 + lane;
+  const int32_t nw = (int32_t)(blockDim.x >> 6);
+  const int64_t slice = blockIdx.x;
+  const int64_t t = slice / (kTile / 64);
+  const int32_t col = (int32_t)(slice % (kTile / 64)) * 64 + lane;
   const int64_t n = t * kTile + col;
 
   double m[S];
   int32_t e[S];
 #pragma unroll
   for (int32_t s = 0; s < S; ++s) {
-    m[s] = a.fresh ? a.fresh_mant : 1.0;
-    e[s] = a.fresh ? a.fresh_exp : 0;
+    m[s] = (a.fresh && wave == 0) ? a.fresh_mant : 1.0;
+    e[s] = (a.fresh && wave == 0) ? a.fresh_exp : 0;
   }
   // partial mantissas lie in [0.5, 1) (or are 0): a few dozen of them multiply without leaving
   // double range, so one renormalisation per group of four loads is plenty
-  for (int32_t ch = 0; ch < (a.fresh ? 0 : a.chunks); ch += 4) {
+  for (int32_t ch = wave * 4; ch < (a.fresh ? 0 : a.chunks); ch += nw * 4) {
     double pm[4][S];
     int32_t pe[4][S];
 #pragma unroll
@@ -174,6 +184,27 @@ __global__ void __launch_bounds__(256) wide_combine_fast(float* __restrict__ are
       int de = 0;
       m[s] = frexp(m[s], &de);
       e[s] += de;
+    }
+  }
+  if (nw > 1) {
+    double* lds_m = reinterpret_cast<double*>(combine_lds);                      // [nw][S][64]
+    int32_t* lds_e = reinterpret_cast<int32_t*>(combine_lds + (size_t)nw * S * 64 * sizeof(double));
+    if (wave > 0) {
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) {
+        lds_m[(wave * S + s) * 64 + lane] = m[s];
+        lds_e[(wave * S + s) * 64 + lane] = e[s];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int32_t w = 1; w < nw; ++w) {
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) {
+        int de = 0;
+        m[s] = frexp(m[s] * lds_m[(w * S + s) * 64 + lane], &de);
+        e[s] += lds_e[(w * S + s) * 64 + lane] + de;
+      }
     }
   }
   // inputs no partial covers

@@ -96,14 +96,6 @@ struct Plan {
   int64_t scratch_elems = 0;
   void* fast = nullptr;  // state of the specialised float32 kernels (dispatch_fast.h), owned by the plan
   void** d_evidence_ptrs = nullptr;  // device array of evidence source addresses
-  // pinned staging for the above: a ring of kStagingSlots tables, each guarded by an event that
-  // marks when its last upload has left it, so that bn_enter_evidence never waits for the device
-  // unless the host runs kStagingSlots calls ahead
-  static constexpr int32_t kStagingSlots = 8;
-  void** h_evidence_ptrs = nullptr;
-  void* staging_events[kStagingSlots] = {};  // hipEvent_t
-  bool staging_used[kStagingSlots] = {};
-  int32_t staging_next = 0;
   std::vector<const void*> evidence_on_device;  // the table d_evidence_ptrs holds (empty = nothing uploaded yet)
   // CPT rows (last axis) of all nodes: start element in the flat CPT buffer and length
   int64_t* d_row_off = nullptr;
