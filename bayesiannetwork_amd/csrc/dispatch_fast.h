@@ -404,6 +404,23 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
                          K, p.ntiles, fresh);
       return launch_ok() ? 1 : -1;
     }
+    // 32 or 64 states: the states split over the eight waves of a block, inputs read once
+    if ((g.num_states == 32 || g.num_states == 64) && g.num_inputs >= 1 && g.num_inputs <= 4) {
+      const dim3 blocks((uint32_t)((int64_t)K * p.ntiles * 2));
+      const bool wide64 = g.num_states == 64;
+      switch (g.num_inputs) {
+#define X(IV)                                                                                                   \
+  case IV:                                                                                                      \
+    if (wide64)                                                                                                 \
+      launch(variable_split_fast<IV, 8>, blocks, dim3(512), 0, s, arena, g.d_in, g.d_out, g.d_c, K, p.ntiles, fresh); \
+    else                                                                                                        \
+      launch(variable_split_fast<IV, 4>, blocks, dim3(512), 0, s, arena, g.d_in, g.d_out, g.d_c, K, p.ntiles, fresh);  \
+    break;
+        X(1) X(2) X(3) X(4)
+#undef X
+      }
+      return launch_ok() ? 1 : -1;
+    }
     // many states (or a shape without a register-resident instance): stream state by state
     const dim3 grid(wave_blocks((int64_t)K * p.ntiles));
     switch (g.num_inputs) {

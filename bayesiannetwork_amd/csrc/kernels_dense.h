@@ -208,6 +208,120 @@ __global__ void __launch_bounds__(256) em_p1_mfma(const float* __restrict__ aren
 }
 
 // ---------------------------------------------------------------------------------
+// Variable pass for nodes with 8*SQ states and a small fan-in I (<= 4), every input read once:
+// a block of eight waves owns (node, 128 observations); wave w keeps states [w*SQ, (w+1)*SQ) of
+// all inputs in registers (two observations per lane, 8-byte accesses), the waves exchange their
+// partial normalisers through LDS, and each writes the outgoing messages of its own states.
+// Same quantities as variable_pass_generic.   grid.x = K * ntiles * 2, block = 512
+template <int I, int SQ>
+__global__ void __launch_bounds__(512) variable_split_fast(float* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                          const int64_t* __restrict__ out_off,
+                                                          const int64_t* __restrict__ c_off, int32_t K,
+                                                          int64_t ntiles, int32_t fresh) {
+  constexpr int32_t NW = 8, S = NW * SQ;
+  __shared__ double part[NW][I + 1][2][64];
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t item = blockIdx.x;  // (node, tile, half tile)
+  const int32_t k = (int32_t)(item / (ntiles * 2));
+  const int64_t rest = item % (ntiles * 2);
+  const int64_t t = rest >> 1;
+  const int32_t col = (int32_t)(rest & 1) * 128 + lane * 2;
+  const float uniform = 1.0f / (float)S;
+
+  float2 in[I][SQ];
+  float* dst[I];
+#pragma unroll
+  for (int32_t i = 0; i < I; ++i) {
+    const int64_t o = out_off[(int64_t)k * I + i];
+    dst[i] = o >= 0 ? arena + o + (t * S + wave * SQ) * kTile + col : nullptr;
+    const bool skip = fresh && o >= 0;  // a message slot that still holds its initial uniform value
+    const float* src = arena + in_off[(int64_t)k * I + i] + (t * S + wave * SQ) * kTile + col;
+#pragma unroll
+    for (int32_t q = 0; q < SQ; ++q)
+      in[i][q] = skip ? make_float2(uniform, uniform) : *reinterpret_cast<const float2*>(src + (int64_t)q * kTile);
+  }
+  // partial normalisers over this wave's states: z = sum_s prod_i in_i[s], sums_i = sum_s prod_{j != i} in_j[s]
+  double z[2] = {0.0, 0.0}, sums[I][2];
+#pragma unroll
+  for (int32_t i = 0; i < I; ++i) sums[i][0] = sums[i][1] = 0.0;
+#pragma unroll
+  for (int32_t q = 0; q < SQ; ++q)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double loo[I], pre = 1.0;
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) {
+        loo[i] = pre;
+        pre *= (double)(v ? in[i][q].y : in[i][q].x);
+      }
+      z[v] += pre;
+      double suf = 1.0;
+#pragma unroll
+      for (int32_t i = I - 1; i >= 0; --i) {
+        sums[i][v] += loo[i] * suf;
+        suf *= (double)(v ? in[i][q].y : in[i][q].x);
+      }
+    }
+#pragma unroll
+  for (int32_t v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) part[wave][i][v][lane] = sums[i][v];
+    part[wave][I][v][lane] = z[v];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int32_t v = 0; v < 2; ++v) {
+    z[v] = 0.0;
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) sums[i][v] = 0.0;
+#pragma unroll
+    for (int32_t w = 0; w < NW; ++w) {
+      z[v] += part[w][I][v][lane];
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) sums[i][v] += part[w][i][v][lane];
+    }
+  }
+  if (wave == 0) {
+    float2 c;
+    int e = 0;
+    double m = frexp(z[0], &e);
+    c.x = (float)((double)e * 0.6931471805599453 + (double)logf((float)m));
+    m = frexp(z[1], &e);
+    c.y = (float)((double)e * 0.6931471805599453 + (double)logf((float)m));
+    *reinterpret_cast<float2*>(arena + c_off[k] + t * kTile + col) = c;
+  }
+#pragma unroll
+  for (int32_t v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int32_t i = 0; i < I - 1; ++i) sums[i][v] = 1.0 / sums[i][v];
+    sums[I - 1][v] = 1.0 / z[v];  // the message to the local factor is normalised by the full product
+  }
+#pragma unroll
+  for (int32_t q = 0; q < SQ; ++q) {
+    float2 out[I];
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double loo[I], pre = 1.0;
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) {
+        loo[i] = pre;
+        pre *= (double)(v ? in[i][q].y : in[i][q].x);
+      }
+      double suf = 1.0;
+#pragma unroll
+      for (int32_t i = I - 1; i >= 0; --i) {
+        const float o = (float)(loo[i] * suf * sums[i][v]);
+        if (v) out[i].y = o; else out[i].x = o;
+        suf *= (double)(v ? in[i][q].y : in[i][q].x);
+      }
+    }
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i)
+      if (dst[i]) *reinterpret_cast<float2*>(dst[i] + (int64_t)q * kTile) = out[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Variable pass for nodes with many states and a small fan-in I (<= 4): one wave per
 // (node, tile), four observations per lane, states streamed one at a time (products are per
 // state; only the normalisers couple states).  Pass 1 accumulates the normalisers, pass 2
