@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) factor_p1_mfma(float* __restrict__ arena,
       for (int32_t jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int32_t r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-#pragma unroll 8
+#pragma unroll
     for (int32_t ks = 0; ks < D0 / 2; ++ks) {
       const int32_t a = 2 * ks + half;
       float bfrag[2];
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) factor_p1_mfma(float* __restrict__ arena,
       for (int32_t jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int32_t r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-#pragma unroll 8
+#pragma unroll
     for (int32_t ks = 0; ks < S / 2; ++ks) {
       const int32_t b = 2 * ks + half;
       float bfrag[2];
