@@ -615,6 +615,40 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   return BN_OK;
 }
 
+int bn_enter_evidence_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
+                             void* stream) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  bn::Plan& p = plan->p;
+  if (p.observed.empty()) return BN_OK;
+  if (!states_dev) return fail(BN_ERR_INVALID, "states_dev is null");
+  if (p.tile % 4 != 0) return fail(BN_ERR_STATE, "observation tile is not a multiple of four");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
+  const size_t count = p.observed.size();
+  {
+    double bytes = 0;
+    for (int32_t o : p.observed) bytes += (double)p.states[o] * (double)p.N * (double)p.elem_size;
+    prof_begin("evidence_from_states", bytes, s);
+  }
+  const uint32_t gx = (uint32_t)((p.npad + 1023) / 1024);
+  for (size_t first = 0; first < count; first += 65535) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
+    if (p.dtype == BN_F32) {
+      bn::launch(bn::evidence_from_states<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
+                 states_dev + (int64_t)first * p.N, p.d_obs_off + first, p.d_obs_states + first, p.N, p.tile, p.npad,
+                 (float)on_value, (float)off_value);
+    } else {
+      bn::launch(bn::evidence_from_states<double>, dim3(gx, cnt), dim3(256), 0, s, static_cast<double*>(p.arena),
+                 states_dev + (int64_t)first * p.N, p.d_obs_off + first, p.d_obs_states + first, p.N, p.tile, p.npad,
+                 on_value, off_value);
+    }
+    BN_LAUNCH_CHECK("evidence_from_states");
+  }
+  p.obs_pending = false;
+  prof_end(s);
+  return BN_OK;
+}
+
 int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   if (num_iterations < 0) return fail(BN_ERR_INVALID, "num_iterations must be >= 0");

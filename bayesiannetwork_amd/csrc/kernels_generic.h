@@ -302,6 +302,45 @@ __global__ void __launch_bounds__(256) evidence_scatter_pairs(float* __restrict_
   *reinterpret_cast<float2*>(dst + tile) = make_float2(x.y, x.w);
 }
 
+// Hard evidence from state indices: row s of the observation slot gets `on` where the observed
+// state is s and `off` elsewhere; four observations per thread (one 4-byte read of the indices,
+// 16-byte stores for float).  grid = (ceil(npad / 1024), num_observed); tile % 4 == 0
+template <typename T>
+__global__ void __launch_bounds__(256) evidence_from_states(T* __restrict__ arena,
+                                                           const uint8_t* __restrict__ states_in,
+                                                           const int64_t* __restrict__ obs_off,
+                                                           const int32_t* __restrict__ obs_states, int64_t N,
+                                                           int32_t tile, int64_t npad, T on, T off) {
+  const int32_t o = blockIdx.y;
+  const int64_t n0 = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  if (n0 >= npad) return;
+  const int32_t S = obs_states[o];
+  const uint8_t* src = states_in + (int64_t)o * N;
+  int32_t st[4];
+  if (n0 + 3 < N && ((reinterpret_cast<uintptr_t>(src + n0) & 3) == 0)) {
+    const uint32_t packed = *reinterpret_cast<const uint32_t*>(src + n0);
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) st[v] = (int32_t)((packed >> (8 * v)) & 0xff);
+  } else {
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) st[v] = n0 + v < N ? (int32_t)src[n0 + v] : -1;  // padding: handled below
+  }
+  const int64_t t = n0 / tile;
+  const int32_t lt = (int32_t)(n0 % tile);
+  T* dst = arena + obs_off[o] + t * S * tile + lt;
+  for (int32_t s = 0; s < S; ++s) {
+    T row[4];
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) row[v] = n0 + v < N ? (st[v] == s ? on : off) : (T)1;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(dst + (int64_t)s * tile) = make_float4(row[0], row[1], row[2], row[3]);
+    } else {
+      *reinterpret_cast<double2*>(dst + (int64_t)s * tile) = make_double2(row[0], row[1]);
+      *reinterpret_cast<double2*>(dst + (int64_t)s * tile + 2) = make_double2(row[2], row[3]);
+    }
+  }
+}
+
 // fill one region with a constant.  grid.x = ceil(count/256)
 template <typename T>
 __global__ void __launch_bounds__(256) fill_region(T* __restrict__ dst, int64_t count, T value) {

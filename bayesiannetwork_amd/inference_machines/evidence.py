@@ -50,6 +50,102 @@ class Evidence:
         )
 
 
+class HardEvidence(Evidence):
+    """Hard (one-hot) evidence kept as one ``uint8`` state index per observed node and observation
+    instead of ``num_states`` floats.  It stands for the tensors
+    ``one_hot(state) * (on_value - off_value) + off_value`` (the soft-clamped one-hot rows the
+    reference's experiments feed in) and hands out exactly those through ``data`` to any
+    ``IInferenceMachine``; a machine that knows the type can consume the indices directly.
+
+    ``states``: integer tensor ``[num_observed_nodes, num_observations]``;
+    ``num_states``: number of states of each observed node, in the same order."""
+
+    def __init__(self, states: torch.Tensor, num_states: Sequence[int], torch_settings: TorchSettings,
+                 on_value: float = 1.0, off_value: float = 0.0):
+        if states.dim() != 2 or states.shape[0] != len(num_states):
+            raise ValueError("states must be [num_observed_nodes, num_observations] with one num_states entry per row")
+        if max(num_states) > 256:
+            raise ValueError("state indices are stored in 8 bits")
+        self.torch_settings = torch_settings
+        self.num_observed_nodes = int(states.shape[0])
+        self.num_observations = int(states.shape[1])
+        self.num_states = [int(s) for s in num_states]
+        self.on_value, self.off_value = float(on_value), float(off_value)
+        self.states = states.to(torch_settings.device, torch.uint8).contiguous()
+        self._expanded = None
+
+    @property
+    def data(self) -> List[torch.Tensor]:
+        if self._expanded is None:
+            dtype = self.torch_settings.dtype
+            on = torch.tensor(self.on_value, dtype=dtype, device=self.states.device)
+            off = torch.tensor(self.off_value, dtype=dtype, device=self.states.device)
+            self._expanded = [
+                torch.where(row.long().unsqueeze(1) == torch.arange(s, device=row.device).unsqueeze(0), on, off)
+                for row, s in zip(self.states, self.num_states)
+            ]
+        return self._expanded
+
+    def __getitem__(self, index) -> "HardEvidence":
+        if isinstance(index, int):
+            index = slice(index, index + 1)
+        return HardEvidence(self.states[:, index], self.num_states, self.torch_settings, self.on_value, self.off_value)
+
+
+class PrefetchingLoader:
+    """Wraps an iterable of evidence batches that live in host memory and moves batch k+1 to the
+    device (pinned staging buffer, side stream) while batch k is being used, so that a training
+    loop never waits for a host-to-device copy it could have overlapped.  ``to_device`` maps a host
+    batch to its device form with ``non_blocking`` copies; the default handles ``Evidence`` and
+    ``HardEvidence``."""
+
+    def __init__(self, batches, device: torch.device, to_device: Callable = None):
+        self._batches = batches
+        self._device = torch.device(device)
+        self._to_device = to_device or self._move
+        self.num_observations = getattr(batches, "num_observations", None)
+
+    def __len__(self) -> int:
+        return len(self._batches)
+
+    def _move(self, batch):
+        ts = TorchSettings(device=self._device.type, dtype=str(batch.torch_settings.dtype).replace("torch.", ""))
+        if isinstance(batch, HardEvidence):
+            states = batch.states if batch.states.is_pinned() or batch.states.is_cuda else batch.states.pin_memory()
+            moved = HardEvidence.__new__(HardEvidence)
+            moved.torch_settings = ts
+            moved.num_observed_nodes, moved.num_observations = batch.num_observed_nodes, batch.num_observations
+            moved.num_states, moved.on_value, moved.off_value = batch.num_states, batch.on_value, batch.off_value
+            moved.states = states.to(self._device, non_blocking=True)
+            moved._expanded = None
+            return moved
+        moved = Evidence.__new__(Evidence)
+        moved.torch_settings = ts
+        moved.num_observed_nodes, moved.num_observations = batch.num_observed_nodes, batch.num_observations
+        moved._data = [(d if d.is_pinned() or d.is_cuda else d.pin_memory()).to(self._device, ts.dtype, non_blocking=True)
+                       for d in batch.data]
+        return moved
+
+    def __iter__(self):
+        if self._device.type != "cuda":
+            yield from self._batches
+            return
+        copy_stream = torch.cuda.Stream(self._device)
+        pending = None
+        for batch in self._batches:
+            with torch.cuda.stream(copy_stream):
+                moved = self._to_device(batch)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            if pending is not None:
+                torch.cuda.current_stream(self._device).wait_event(pending[1])
+                yield pending[0]
+            pending = (moved, ready)
+        if pending is not None:
+            torch.cuda.current_stream(self._device).wait_event(pending[1])
+            yield pending[0]
+
+
 class EvidenceLoader:
     def __init__(self, data_loader, transform: Callable[[torch.Tensor], Evidence]):
         self._data_loader = data_loader

@@ -51,6 +51,8 @@ def _declare(lib):
     lib.bn_reset_messages.argtypes = [c_void_p, c_void_p]
     lib.bn_enter_evidence.restype = c_int
     lib.bn_enter_evidence.argtypes = [c_void_p, POINTER(c_void_p), c_void_p]
+    lib.bn_enter_evidence_states.restype = c_int
+    lib.bn_enter_evidence_states.argtypes = [c_void_p, c_void_p, c_double, c_double, c_void_p]
     lib.bn_iterate.restype = c_int
     lib.bn_iterate.argtypes = [c_void_p, c_int32, c_void_p]
     lib.bn_log_likelihood.restype = c_int
@@ -80,7 +82,7 @@ def _declare(lib):
 EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
-    "bn_enter_evidence", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
+    "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_m_step", "bn_get_message",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only",
 )

@@ -21,7 +21,7 @@ import torch
 from ...bayesian_network import BayesianNetwork, Node
 from ..abstractions import IInferenceMachine
 from ..common import InferenceMachineSettings
-from ..evidence import Evidence
+from ..evidence import Evidence, HardEvidence
 from . import _native
 
 
@@ -255,6 +255,8 @@ class HipSpaInferenceMachine(IInferenceMachine):
 
     # ------------------------------------------------------------------ interface
     def enter_evidence(self, evidence: Evidence) -> None:
+        if isinstance(evidence, HardEvidence):
+            return self._enter_hard_evidence(evidence)
         key = (self._device, self._dtype, self._n)
         cached = getattr(evidence, "_hip_table", None)
         if cached is None or cached[0] != key:
@@ -280,6 +282,25 @@ class HipSpaInferenceMachine(IInferenceMachine):
         with torch.cuda.device(self._device):
             _native.check(self._lib.bn_enter_evidence(self._plan, cached[2], self._stream()))
         self._evidence_keepalive = cached
+        self.must_iterate = True
+
+    def _enter_hard_evidence(self, evidence: HardEvidence) -> None:
+        """State indices go to the engine as they are (one byte per observed node and observation);
+        the observation slots end up holding exactly ``evidence.data``."""
+        states = evidence.states
+        if states.device != self._device:
+            states = states.to(self._device)
+        if tuple(states.shape) != (len(self.observed_nodes), self._n):
+            raise RuntimeError(f"hard evidence has shape {tuple(states.shape)}, expected "
+                               f"{(len(self.observed_nodes), self._n)}")
+        if evidence.num_states != [int(node.num_states) for node in self.observed_nodes]:
+            raise RuntimeError("hard evidence was built for other state counts than the observed nodes have")
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_enter_evidence_states(self._plan, ctypes.c_void_p(states.data_ptr()),
+                                                   evidence.on_value, evidence.off_value, self._stream())
+            )
+        self._evidence_keepalive = states
         self.must_iterate = True
 
     def _iterate(self) -> None:

@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="observations per GPU per step")
     ap.add_argument("--model", choices=["c3a", "c3b", "c5"], default="c3a")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
+    ap.add_argument("--evidence", choices=["resident", "host-float", "host-uint8"], default="resident",
+                    help="resident: batches already in HBM (the contract's figure).  host-*: batches start in host "
+                         "memory every step and cross PCIe through PrefetchingLoader (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -214,7 +217,30 @@ def main():
 
     logger = OptimizerLogger()
 
+    host_batches = None
+    if args.evidence != "resident":
+        from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence, PrefetchingLoader
+        host_ts = TorchSettings(device="cpu", dtype=args.dtype)
+        host_batches = []
+        for b in batches:
+            if args.evidence == "host-uint8":
+                # the synthetic evidence is hard: state = argmax, on / off = the two values it takes
+                states = torch.stack([d.argmax(dim=1) for d in b.data]).cpu()
+                hard = HardEvidence(states, [d.shape[1] for d in b.data], host_ts,
+                                    on_value=float(b.data[0].max()), off_value=float(b.data[0].min()))
+                hard.states = hard.states.pin_memory()
+                host_batches.append(hard)
+            else:
+                host_batches.append(Evidence([d.cpu().pin_memory() for d in b.data], host_ts))
+
     def run(steps):
+        if host_batches is not None:
+            opt = EmBatchOptimizer(
+                network, factory,
+                EmBatchOptimizerSettings(learning_rate=0.1, num_epochs=1, regularization=0.01,
+                                         sharded=world > 1, deferred_logging=True), logger)
+            opt.optimize(PrefetchingLoader(_Batches([host_batches[i % 2] for i in range(steps)], n * steps), device))
+            return
         opt = EmBatchOptimizer(
             network, factory,
             EmBatchOptimizerSettings(learning_rate=0.1, num_epochs=1, regularization=0.01,
@@ -287,6 +313,7 @@ def main():
                              "c5": "depth-6 binary tree of 64-state hidden nodes + 32 observed 64-state leaves"}[args.model]
                 + f", EM step (T={t_used} flooding iterations + ll + expected counts + M-step)",
                 "batch_per_gpu": n,
+                "evidence": args.evidence,
                 "global_batch": n * world,
                 "learning_rate": 0.1,
                 "regularization": 0.01,

@@ -108,6 +108,18 @@ int bn_reset_messages(bn_plan* plan, void* stream);
 int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stream);
 
 /*
+ * Compact hard evidence: states_dev[o * num_observations + n] (uint8) is the observed state of
+ * the o-th observed node in observation n.  Writes on_value into that state's row of the node's
+ * observation slot and off_value into its other rows: exactly the tensor
+ * one_hot(state) * (on_value - off_value) + off_value that Evidence would have carried
+ * (inference_machines/evidence.py:8-45; the soft-clamped one-hot evidence of
+ * dev_experiments), at one byte per observed node and observation instead of 4 * num_states.
+ * A state >= the node's number of states leaves all rows at off_value.
+ */
+int bn_enter_evidence_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
+                             void* stream);
+
+/*
  * Run num_iterations flooding iterations: all variable-to-factor updates, then
  * all factor-to-variable updates.  Replaces FactorGraph.iterate,
  * VariableNodeGroup.calculate_outputs and FactorNodeGroup.calculate_outputs

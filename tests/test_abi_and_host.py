@@ -143,3 +143,34 @@ def test_evidence_and_loader():
     batches = list(loader)
     assert len(loader) == 2 and loader.num_observations == 10
     assert batches[1].num_observed_nodes == 4 and batches[1].data[0][0, 1] == 1
+
+
+def test_hard_evidence_stands_for_its_one_hot_tensors():
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence, PrefetchingLoader
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cpu", dtype="float64")
+    gen = torch.Generator().manual_seed(5)
+    num_states = [2, 3, 5]
+    states = torch.stack([torch.randint(0, s, (11,), generator=gen) for s in num_states])
+    hard = HardEvidence(states, num_states, ts, on_value=1 - 1e-6, off_value=5e-7)
+    assert len(hard) == 11 and hard.num_observed_nodes == 3
+    for row, s, got in zip(states, num_states, hard.data):
+        want = torch.nn.functional.one_hot(row, s).double() * ((1 - 1e-6) - 5e-7) + 5e-7
+        assert got.shape == (11, s) and got.dtype == torch.float64
+        # on / off are written as given, not recomputed: the one-hot formula agrees to rounding
+        torch.testing.assert_close(got, want, rtol=0, atol=1e-15)
+        assert set(got.unique().tolist()) <= {1 - 1e-6, 5e-7}
+    part = hard[3:7]
+    assert isinstance(part, HardEvidence) and len(part) == 4
+    for a, b in zip(part.data, hard.data):
+        assert torch.equal(a, b[3:7])
+    assert torch.equal(hard.get_observation(2), torch.stack(hard[2].data)) if len(set(num_states)) == 1 else True
+    # usable wherever an Evidence is: same type hierarchy, same members
+    assert isinstance(hard, Evidence)
+    with pytest.raises(ValueError):
+        HardEvidence(states, [2, 3], ts)
+    # on a CPU device the prefetching loader is a plain pass-through, in order
+    batches = [hard[0:4], hard[4:8], hard[8:11]]
+    assert [b is c for b, c in zip(PrefetchingLoader(batches, "cpu"), batches)] == [True, True, True]
+    assert len(PrefetchingLoader(batches, "cpu")) == 3

@@ -218,3 +218,77 @@ def test_m_step_kernel_equals_the_tensor_formulas(dtype, lr, reg):
         pos += size
     rows = torch.cat([v.reshape(-1, v.shape[-1]).sum(-1) for v in model.views(got)])
     torch.testing.assert_close(rows, torch.ones_like(rows), rtol=0, atol=1e-6 if dtype == "float32" else 1e-14)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n", [5, 300, 1027])
+def test_hard_evidence_fills_the_observation_slots_like_its_tensors(dtype, n):
+    """bn_enter_evidence_states: the slots must hold, bit for bit, what entering HardEvidence.data
+    through the tensor path puts there, and every result downstream must be identical."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    torch.manual_seed(11)
+    q = Node.random((4,), ts, "Q")
+    kids = [Node.random((4, s), ts, f"Y{i}") for i, s in enumerate([2, 2, 3, 5, 2, 7])]
+    net = BayesianNetworkBuilder().add_node(q).add_nodes(kids, q).build()
+    gen = torch.Generator().manual_seed(n)
+    states = torch.stack([torch.randint(0, k.num_states, (n,), generator=gen) for k in kids])
+    hard = HardEvidence(states, [k.num_states for k in kids], ts, on_value=0.999999 + 5e-7, off_value=5e-7)
+
+    compact = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), net, kids, n)
+    compact.enter_evidence(hard)
+    dense = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), net, kids, n)
+    dense.enter_evidence(Evidence(hard.data, ts))
+    for node, want in zip(kids, hard.data):
+        assert torch.equal(compact.observation(node), want), node.name
+        assert torch.equal(dense.observation(node), want), node.name
+    for a, b in zip(compact.infer_single_nodes(list(net.nodes)), dense.infer_single_nodes(list(net.nodes))):
+        assert torch.equal(a, b)
+    assert compact.log_likelihood() == dense.log_likelihood()
+    with pytest.raises(RuntimeError):
+        compact.enter_evidence(hard[0:2] if n > 2 else HardEvidence(states[:, :1].repeat(1, n + 1), hard.num_states, ts))
+
+
+def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory():
+    """Host-resident uint8 batches through PrefetchingLoader give the same EM trajectory as the same
+    evidence resident on the device as float tensors."""
+    import copy
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence, PrefetchingLoader
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers import EmBatchOptimizer, EmBatchOptimizerSettings, OptimizerLogger
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype="float32")
+    host = TorchSettings(device="cpu", dtype="float32")
+    n, batches = 200, 4
+
+    def build():
+        torch.manual_seed(2)
+        q = Node.random((5,), ts, "Q")
+        kids = [Node.random((5, 2), ts, f"Y{i}") for i in range(30)]
+        return BayesianNetworkBuilder().add_node(q).add_nodes(kids, q).build(), kids
+
+    gen = torch.Generator().manual_seed(9)
+    host_batches = [HardEvidence(torch.randint(0, 2, (30, n), generator=gen), [2] * 30, host, 0.9999995, 5e-7)
+                    for _ in range(batches)]
+    results = []
+    for mode in ("prefetched", "resident"):
+        net, kids = build()
+        logger = OptimizerLogger()
+        opt = EmBatchOptimizer(
+            net, lambda network: HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), network, kids, n),
+            EmBatchOptimizerSettings(learning_rate=0.2, num_epochs=2, regularization=0.01), logger)
+        if mode == "prefetched":
+            loader = PrefetchingLoader(host_batches, "cuda")
+        else:
+            loader = [Evidence([d.to("cuda") for d in b.data], ts) for b in host_batches]
+        opt.optimize(loader)
+        results.append(([log.ll for log in logger.logs], [node.cpt.clone() for node in net.nodes]))
+    assert results[0][0] == results[1][0]
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
