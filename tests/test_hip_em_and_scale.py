@@ -292,3 +292,39 @@ def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory():
     assert results[0][0] == results[1][0]
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.equal(a, b)
+
+
+def test_full_batch_em_never_lowers_the_likelihood_on_sampled_data():
+    """Property of exact EM on a tree (the 784-leaf model's shape at 60 leaves): on data sampled from a
+    ground-truth network with the batched sampler, every full-batch EM iteration raises the
+    log-likelihood (up to float32 rounding of the mean)."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers import EmOptimizer, EmOptimizerSettings, OptimizerLogger
+    from bayesiannetwork_amd.samplers import BatchedBayesianNetworkSampler
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype="float32")
+    n, leaves = 20000, 60
+
+    def build(seed):
+        torch.manual_seed(seed)
+        q = Node.random((10,), ts, "Q")
+        ys = [Node.random((10, 2), ts, f"Y{i}") for i in range(leaves)]
+        return BayesianNetworkBuilder().add_node(q).add_nodes(ys, q).build(), ys
+
+    truth, truth_ys = build(1)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    states = BatchedBayesianNetworkSampler(truth, ts, gen).sample(n, truth_ys)  # [n, leaves]
+    evidence = HardEvidence(states.t().contiguous(), [2] * leaves, ts, on_value=0.9999995, off_value=5e-7)
+
+    model, ys = build(2)
+    logger = OptimizerLogger()
+    EmOptimizer(model, lambda net: HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), net, ys, n),
+                EmOptimizerSettings(num_iterations=8), logger).optimize(evidence)
+    lls = [log.ll for log in logger.logs]
+    assert len(lls) == 8
+    for before, after in zip(lls, lls[1:]):
+        assert after >= before - 1e-5 * abs(before), lls
+    assert lls[-1] > lls[0] + 0.1
