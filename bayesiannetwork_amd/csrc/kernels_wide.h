@@ -555,6 +555,19 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     }
   }
 
+  // loop mode keeps the leaves' normalisers out of the per-state products: prod_k (q_k / z_k) is
+  // carried as prod_k q_k per state and prod_k z_k per observation, divided once at the end
+  fv<V> pf_sum = pf[0];
+#pragma unroll
+  for (int32_t i = 1; i < D0; ++i) pf_sum += pf[i];
+  double pz[V];
+  int32_t pze[V];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) {
+    pz[v] = 1.0;
+    pze[v] = 0;
+  }
+
   double ll_acc[V];
 #pragma unroll
   for (int32_t v = 0; v < V; ++v) ll_acc[v] = 0.0;
@@ -593,6 +606,49 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       inv_sum += r[i];
     }
     inv_sum = rcpv<V>(inv_sum);
+    if constexpr (!FULL && !REDUCE) {
+      // Loop mode needs neither message explicitly.  The leaf's next normaliser is
+      //   z' = sum_s ev[s] * (cpt^T t)[s] = sum_i t[i] * q[i],  t = r / sum r,
+      // which in the steady state (r = P'/q) is sum(P') / sum(r).
+      fv<V> zn;
+      if constexpr (STATE == kLeafSteady) {
+        zn = pf_sum * inv_sum;
+      } else {
+        zn = r[0] * q[0];
+#pragma unroll
+        for (int32_t i = 1; i < D0; ++i) zn = __builtin_elementwise_fma(r[i], q[i], zn);
+        zn *= inv_sum;
+      }
+      storev<V>(ptr.z, t, col, zn);
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+#pragma unroll
+        for (int32_t i = 0; i < D0; ++i) pm[i][v] *= (double)q[i][v];
+        pz[v] *= (double)cur.z[v];
+      }
+      if (((k - first) & 3) == 3) {
+#pragma unroll
+        for (int32_t i = 0; i < D0; ++i) {
+          ev_t<V> de_v;
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) {
+            int de = 0;
+            pm[i][v] = frexp(pm[i][v], &de);
+            de_v[v] = de;
+          }
+          pe[i] += de_v;
+        }
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          pz[v] = frexp(pz[v], &de);
+          pze[v] += de;
+        }
+      }
+      ptr = ptr_next;
+      cur = nxt;
+      continue;
+    }
     // own (leaf) variable: c = log z, message to the factor = ev / z
     const fv<V> inv_z = recipv<V>(cur.z);
     if (FULL || REDUCE) {
@@ -657,15 +713,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     for (int32_t i = 1; i < D0; ++i)
 #pragma unroll
       for (int32_t j = 0; j < S; ++j) new_own[j] = __builtin_elementwise_fma(splat<V>(cpt[i * S + j]), r[i], new_own[j]);
-    if (FULL) {
 #pragma unroll
-      for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
-    } else {
-      // r was left un-normalised in loop mode: one scale of the S sums instead of D0 messages
-#pragma unroll
-      for (int32_t j = 0; j < S; ++j) new_own[j] *= inv_sum;
-      storev<V>(ptr.z, t, col, leaf_normaliser<S, V>(cur.ev, new_own));
-    }
+    for (int32_t j = 0; j < S; ++j) storev<V>(ptr.f2v_own, t * S + j, col, new_own[j]);
     // fold into the partial product for the parent's next combine
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i)
@@ -693,14 +742,21 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     for (int32_t v = 0; v < V; ++v) dst[v] = ll_acc[v];
     return;
   }
+  double inv_pz[V];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) {
+    int de = 0;
+    inv_pz[v] = 1.0 / frexp(pz[v], &de);  // pz stayed 1 in full mode
+    pze[v] += de;
+  }
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
     int32_t ex[V];
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {
       int de = 0;
-      pm[s][v] = frexp(pm[s][v], &de);
-      ex[v] = (int32_t)pe[s][v] + de;
+      pm[s][v] = frexp(pm[s][v] * inv_pz[v], &de);
+      ex[v] = (int32_t)pe[s][v] + de - pze[v];
     }
     const int64_t row = ((int64_t)chunk * D0 + s) * a.npad + t * kTile + col;
     if constexpr (V == 4) {
