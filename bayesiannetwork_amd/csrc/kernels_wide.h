@@ -381,6 +381,45 @@ __device__ __forceinline__ float wave_sum_lane63(float x) {
   return x;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sums E per-lane values over the 64 lanes of the wave with fewer operations than E full
+// reductions: the first two steps are a reduce-scatter inside each quad (after them a lane only
+// carries a quarter of the entries: those of its position in the quad), the rest adds the 16
+// quads (row rotations, then the two cross-row exchanges).  Afterwards lane q < 4 holds in
+// out[f] the total of entry index wave_sum_entry<E>(q, f) (or nothing if that is >= E).
+template <int E>
+struct WaveSums {
+  static constexpr int H1 = (E + 1) / 2, H2 = (H1 + 1) / 2;
+  float out[H2];
+  __device__ __forceinline__ static int32_t entry(int32_t q, int32_t f) {
+    const int32_t e = f + ((q >> 1) & 1) * H2;  // index after the first step
+    return e < H1 ? e + (q & 1) * H1 : E;
+  }
+  __device__ __forceinline__ void reduce(const float (&p)[E], int32_t lane) {
+    const bool odd = lane & 1, upper = lane & 2;
+    float y[H1];
+#pragma unroll
+    for (int32_t e = 0; e < H1; ++e) {
+      const float a = p[e], b = e + H1 < E ? p[e + H1] : 0.f;
+      y[e] = (odd ? b : a) + dpp_move<0xB1>(odd ? a : b);  // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int32_t f = 0; f < H2; ++f) {
+      const float a = y[f], b = f + H2 < H1 ? y[f + H2] : 0.f;
+      float w = (upper ? b : a) + dpp_move<0x4E>(upper ? a : b);  // quad_perm [2,3,0,1]
+      w += dpp_move<0x124>(w);                                     // row_ror:4
+      w += dpp_move<0x128>(w);                                     // row_ror:8
+      w += __shfl_xor(w, 16, 64);
+      w += __shfl_xor(w, 32, 64);
+      out[f] = w;
+    }
+  }
+};
+
 // 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
 // seed plus one Newton step.
 __device__ __forceinline__ double recip(double x) {
@@ -568,9 +607,6 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
     pze[v] = 0;
   }
 
-  double ll_acc[V];
-#pragma unroll
-  for (int32_t v = 0; v < V; ++v) ll_acc[v] = 0.0;
   LeafPtrs ptr = leaf_ptrs(arena, cpts, a, first);
   LeafState<S, V> cur = leaf_state<S, V, STATE>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
@@ -649,18 +685,67 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       cur = nxt;
       continue;
     }
+    if constexpr (REDUCE) {
+      // sum_k log z_k = log prod_k z_k: the product is carried like in loop mode, one log at the end
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) pz[v] *= (double)cur.z[v];
+      if (((k - first) & 3) == 3) {
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          pz[v] = frexp(pz[v], &de);
+          pze[v] += de;
+        }
+      }
+      if (a.em_partial) {
+        // EM counts of this family over the wave's observations (padding masked), wave-reduced:
+        // sum_n t[i] * o[j] with t = r / sum r and o = ev / z; both scalings go onto the S-vector
+        const fv<V> scale = recipv<V>(cur.z) * inv_sum;
+        fv<V> o[S];
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) {
+          o[j] = cur.ev[j] * scale;
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v)
+            if (t * kTile + col + v >= a.N) o[j][v] = 0.f;
+        }
+        float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
+        float per_lane[D0 * S];
+#pragma unroll
+        for (int32_t i = 0; i < D0; ++i)
+#pragma unroll
+          for (int32_t j = 0; j < S; ++j) {
+            const fv<V> prod = r[i] * o[j];
+            float x = prod[0];
+#pragma unroll
+            for (int32_t v = 1; v < V; ++v) x += prod[v];
+            per_lane[i * S + j] = x;
+          }
+        WaveSums<D0 * S> sums;
+        sums.reduce(per_lane, lane);
+        if (lane < 4) {
+#pragma unroll
+          for (int32_t f = 0; f < WaveSums<D0 * S>::H2; ++f) {
+            const int32_t e = WaveSums<D0 * S>::entry(lane, f);
+            if (e < D0 * S) dst[(int64_t)e * a.slots] = sums.out[f];
+          }
+        }
+      }
+      ptr = ptr_next;
+      cur = nxt;
+      continue;
+    }
     // own (leaf) variable: c = log z, message to the factor = ev / z
     const fv<V> inv_z = recipv<V>(cur.z);
-    if (FULL || REDUCE) {
+    {
       fv<V> c;
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         int de = 0;
         const float mz = frexpf(cur.z[v], &de);
         c[v] = (float)((double)de * 0.6931471805599453 + (double)logf(mz));
-        if (REDUCE) ll_acc[v] += (double)c[v];
       }
-      if (FULL) storev<V>(ptr.c, t, col, c);
+      storev<V>(ptr.c, t, col, c);
     }
     fv<V> new_par[D0], new_own[S];
 #pragma unroll
@@ -671,34 +756,6 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
       for (int32_t j = 0; j < S; ++j) to_f_own[j] = cur.ev[j] * inv_z;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) r[i] *= inv_sum;  // now the normalised message
-      if constexpr (REDUCE) {
-        if (!a.em_partial) {  // only the log-likelihood sums are wanted
-          ptr = ptr_next;
-          cur = nxt;
-          continue;
-        }
-        // EM counts of this family over the wave's observations (padding masked), wave-reduced
-#pragma unroll
-        for (int32_t j = 0; j < S; ++j)
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v)
-            if (t * kTile + col + v >= a.N) to_f_own[j][v] = 0.f;
-        float* dst = a.em_partial + ((int64_t)k * (D0 * S)) * a.slots + (t * kParts + part);
-#pragma unroll
-        for (int32_t i = 0; i < D0; ++i)
-#pragma unroll
-          for (int32_t j = 0; j < S; ++j) {
-            const fv<V> prod = r[i] * to_f_own[j];
-            float x = prod[0];
-#pragma unroll
-            for (int32_t v = 1; v < V; ++v) x += prod[v];
-            x = wave_sum_lane63(x);
-            if (lane == 63) dst[(int64_t)(i * S + j) * a.slots] = x;
-          }
-        ptr = ptr_next;
-        cur = nxt;
-        continue;
-      }
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) storev<V>(ptr.v2f_par, t * D0 + i, col, r[i]);
 #pragma unroll
@@ -739,7 +796,11 @@ __global__ void __launch_bounds__(256) leaf_family_p1(float* __restrict__ arena,
   if constexpr (REDUCE) {
     double* dst = a.ll_part + (int64_t)chunk * a.npad + t * kTile + col;
 #pragma unroll
-    for (int32_t v = 0; v < V; ++v) dst[v] = ll_acc[v];
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      const double m = frexp(pz[v], &de);
+      dst[v] = (double)(pze[v] + de) * 0.6931471805599453 + log(m);
+    }
     return;
   }
   double inv_pz[V];
@@ -923,6 +984,7 @@ __global__ void __launch_bounds__(256) leaf_family_p2(float* __restrict__ arena,
         for (int32_t v = 0; v < V; ++v)
           if (t * kTile + col + v >= a.N) o[j][v] = 0.f;
       float* dst = a.em_partial + ((int64_t)k * (D0 * D1 * S)) * a.slots + (t * kParts + part);
+      float per_lane[D0 * D1 * S];
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
@@ -934,10 +996,18 @@ __global__ void __launch_bounds__(256) leaf_family_p2(float* __restrict__ arena,
             float x = prod[0];
 #pragma unroll
             for (int32_t v = 1; v < V; ++v) x += prod[v];
-            x = wave_sum_lane63(x);
-            if (lane == 63) dst[(int64_t)((i * D1 + l) * S + j) * a.slots] = x;
+            per_lane[(i * D1 + l) * S + j] = x;
           }
         }
+      WaveSums<D0 * D1 * S> sums;
+      sums.reduce(per_lane, lane);
+      if (lane < 4) {
+#pragma unroll
+        for (int32_t f = 0; f < WaveSums<D0 * D1 * S>::H2; ++f) {
+          const int32_t e = WaveSums<D0 * D1 * S>::entry(lane, f);
+          if (e < D0 * D1 * S) dst[(int64_t)e * a.slots] = sums.out[f];
+        }
+      }
       continue;
     }
     // contractions: A[i][l] = sum_j cpt[i][l][j] o[j];  m1 = A t2;  m2 = A^T t1;  own = cpt^T (t1 x t2)
