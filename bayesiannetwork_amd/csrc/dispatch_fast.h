@@ -365,8 +365,13 @@ inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double&
   }
   bytes += 2.0 * w.S * (double)w.covered.size() * (double)p.N * (double)p.elem_size +
            leaf * (double)p.N * (double)p.elem_size;
-  label = "leaf_family[" + std::to_string(g.dims[0]) + "x" + std::to_string(g.dims[1]) +
-          ",K=" + std::to_string(g.nodes.size()) + "]";
+  if (it->second.wide_index2 >= 0) {
+    const WideNode& w2 = st->wide[it->second.wide_index2];
+    bytes += 2.0 * w2.S * (double)w2.covered.size() * (double)p.N * (double)p.elem_size;
+  }
+  label = "leaf_family[";
+  for (size_t d = 0; d < g.dims.size(); ++d) label += (d ? "x" : "") + std::to_string(g.dims[d]);
+  label += ",K=" + std::to_string(g.nodes.size()) + "]";
   return true;
 }
 

@@ -30,12 +30,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def pmc_traffic(kernel_label: str):
+def pmc_traffic(kernel_label: str, model: str = "c3a"):
     """HBM bytes per launch of the kernel behind a profile label, from the committed rocprofv3
     --pmc summary (tools/pmc_traffic.sh; FETCH_SIZE / WRITE_SIZE passes of this same command).
     None when no summary covers the kernel."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not os.path.exists(path):
+    if model != "c3a" or not os.path.exists(path):  # the committed passes ran the default (784-leaf) command
         return None
     table = json.load(open(path))
     stem = {"leaf_family": "bn::leaf_family_p1", "factor_pass": "bn::factor_p", "em_counts": "bn::em_p",
@@ -292,7 +292,7 @@ def main():
             avg_s = dom["total_ms"] / dom["launches"] / 1e3
             achieved = dom["alg_bytes"] / avg_s / 1e9
             roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dom["kernel"]), avg_launch_ms=avg_s * 1e3,
+                            frac=achieved / HBM_PEAK_GBS, traffic=pmc_traffic(dom["kernel"], args.model), avg_launch_ms=avg_s * 1e3,
                             alg_bytes_per_launch=dom["alg_bytes"])
         out = {
             "metric": "evidence samples/sec (sum-product infer + EM step), MNIST 784-leaf latent model",

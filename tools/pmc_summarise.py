@@ -31,6 +31,16 @@ def per_kernel(counter):
 
 
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+
+# calibration of the leaf-family kernel's 8-byte-per-lane pattern on its fresh-state instantiation
+# (MODE 3 = loop mode, fresh state) at the default bench geometry: 784 families x 60 160 padded
+# observations x 2 evidence floats + 10 doubles of the parent product per observation
+LEAF_FACTOR = 1.78
+for name, values in fetch.items():
+    if "leaf_family_p1<10, 2, 2, 3>" in name and values:
+        known = 784 * 60160 * 8 + 10 * 60160 * 8
+        LEAF_FACTOR = known / (1024.0 * sum(values) / len(values))
+        print(f"leaf-family fetch calibration: x{LEAF_FACTOR:.3f}")
 result = {}
 for name in sorted(set(fetch) | set(write)):
     if "bn::" not in name:
@@ -44,7 +54,7 @@ for name in sorted(set(fetch) | set(write)):
               or re.search(r"leaf_family_p1<\d+, \d+, [12], \d+>", short) is not None)
     factor = 1.0 if narrow else 2.0
     if "leaf_family_p1" in short:
-        factor = 1.78
+        factor = LEAF_FACTOR
     result[short] = dict(
         launches=len(f),
         fetch_correction=factor,
