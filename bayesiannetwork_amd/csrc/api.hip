@@ -437,7 +437,7 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
   {
     // room for more chunks per entry when only a few nodes need partial sums (at most 32 MiB extra)
     const int64_t generous = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)(4 << 20) / std::max<int64_t>(p.cpt_total, 1)));
-    p.scratch_elems = kLlBlocks + p.cpt_total * std::max<int64_t>(em_chunks(p), generous) + bn::fast_scratch_elems(p);
+    p.scratch_elems = kLlBlocks + p.cpt_total * std::max<int64_t>(em_chunks(p), generous);
   }
   BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.scratch), (size_t)p.scratch_elems * sizeof(double)));
   p.device_bytes += p.scratch_elems * 8;

@@ -90,8 +90,6 @@ inline bool is_wide_group(const Plan& p, const VariableGroup& g) {
   return p.dtype == 0 && g.num_inputs > kWideFanIn && small_dim(g.num_states);
 }
 
-inline int64_t fast_scratch_elems(const Plan&) { return 0; }
-
 template <typename U>
 inline bool dev_upload(const std::vector<U>& host, U** dev, int64_t& bytes) {
   *dev = nullptr;
@@ -507,8 +505,6 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.scaled = w.scaled;
   a.npad = p.npad;
   a.ntiles = p.ntiles;
-  a.fresh = fresh;
-  a.prev_from_arrays = first_iteration;
   a.N = p.N;
   a.z_state = fam.z_state;
   a.em_partial = with_counts ? fam.em_partial : nullptr;

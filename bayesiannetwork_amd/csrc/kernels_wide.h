@@ -332,10 +332,6 @@ struct LeafFamilyArgs {
   const double* scaled;  // parent's P'
   int64_t npad;
   int64_t ntiles;
-  int32_t fresh;
-  // first iteration of a bn_iterate call: the factor's previous message to the parent is read
-  // from its array; later iterations rebuild it from the leaf's previous normaliser (see kernel)
-  int32_t prev_from_arrays;
   float* z_state;  // [K][npad] loop state: the leaf's normaliser z for the coming iteration
   // kLeafReduce only
   int64_t N;
@@ -364,22 +360,6 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 //   kLeafFresh       nothing has been sent yet: every message still has its initial uniform value;
 //   kLeafFromArrays  the message arrays a kLeafFull launch wrote.
 constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2;
-
-// Sum over the 64 lanes with data-parallel-primitive adds only (no LDS crossbar): quad swaps,
-// row (16-lane) mirrors, then the row broadcasts.  The total ends up in lane 63.
-__device__ __forceinline__ float wave_sum_lane63(float x) {
-  auto dpp = [](float v, auto ctrl, auto row_mask) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
-                                                                decltype(row_mask)::value, 0xF, true));
-  };
-  x += dpp(x, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
-  x += dpp(x, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
-  x += dpp(x, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
-  x += dpp(x, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror
-  x += dpp(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 -> rows 1,3
-  x += dpp(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 -> rows 2,3
-  return x;
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -419,14 +399,6 @@ struct WaveSums {
     }
   }
 };
-
-// 1/x for a double that came from a float (never subnormal as a double): hardware reciprocal
-// seed plus one Newton step.
-__device__ __forceinline__ double recip(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return fma(fma(-x, r, 1.0), r, r);
-}
 
 // V floats of one lane as a hardware vector: arithmetic on it compiles to the packed
 // two-float instructions (v_pk_mul/add/fma_f32) when V is even.
