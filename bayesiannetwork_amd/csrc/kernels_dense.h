@@ -32,8 +32,10 @@ __device__ __forceinline__ int32_t mfma_row(int32_t reg, int32_t lane) {
 // One workgroup (4 waves) per (node, tile); wave w owns observations [64w, 64w+64).
 //   to own variable  out_own^T[b][n] = sum_a cpt[a][b] * in_par^T[a][n]
 //   to parent        out_par^T[a][n] = sum_b cpt[a][b] * in_own^T[b][n]
+// At least three waves per SIMD (<= 168 VGPRs): with the k loops fully unrolled the compiler would
+// take a few registers more and drop to two, which costs more than the tighter allocation does.
 template <int D0, int S>
-__global__ void __launch_bounds__(256) factor_p1_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) factor_p1_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
                                                      const int64_t* __restrict__ in_off,
                                                      const int64_t* __restrict__ out_off,
                                                      const int64_t* __restrict__ cpt_off, int32_t K,
