@@ -175,6 +175,7 @@ void release(bn::Plan& p) {
   if (p.d_obs_states) (void)hipFree(p.d_obs_states);
   if (p.d_fill_off) (void)hipFree(p.d_fill_off);
   if (p.d_fill_states) (void)hipFree(p.d_fill_states);
+  if (p.c_before) (void)hipFree(p.c_before);
   if (p.d_row_off) (void)hipFree(p.d_row_off);
   if (p.d_row_len) (void)hipFree(p.d_row_len);
 }
@@ -220,6 +221,7 @@ int reset_messages_t(bn::Plan& p, hipStream_t s) {
   (void)arena;
   (void)s;
   p.c_stale = true;  // zeroed on demand: every iteration overwrites all of them anyway
+  p.c_before_valid = false;
   p.fresh = true;
   bn::invalidate_fast(p);
   return BN_OK;
@@ -681,6 +683,36 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
   bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, scale, out_dev);
   BN_LAUNCH_CHECK("sum_partials");
   prof_end(s);
+  return BN_OK;
+}
+
+int bn_normaliser_change(bn_plan* plan, double* out_dev, void* stream) {
+  if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = complete_pending(p, s)) return rc;
+  if (int rc = settle_normalisers(p, s)) return rc;
+  const int64_t total = (int64_t)p.n_nodes * p.npad;
+  if (!p.c_before) {
+    BN_HIP_CHECK(hipMalloc(&p.c_before, (size_t)total * p.elem_size));
+    p.device_bytes += total * (int64_t)p.elem_size;
+    p.c_before_valid = false;
+  }
+  const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
+  const int32_t before_is_zero = p.c_before_valid ? 0 : 1;
+  if (p.dtype == BN_F32) {
+    bn::launch(bn::normaliser_change_partial<float>, dim3(blocks), dim3(256), 0, s,
+               static_cast<const float*>(p.arena) + p.c_base, static_cast<float*>(p.c_before), before_is_zero,
+               (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  } else {
+    bn::launch(bn::normaliser_change_partial<double>, dim3(blocks), dim3(256), 0, s,
+               static_cast<const double*>(p.arena) + p.c_base, static_cast<double*>(p.c_before), before_is_zero,
+               (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  }
+  BN_LAUNCH_CHECK("normaliser_change_partial");
+  bn::launch(bn::max_partials, dim3(1), dim3(256), 0, s, p.scratch, blocks, out_dev);
+  BN_LAUNCH_CHECK("max_partials");
+  p.c_before_valid = true;
   return BN_OK;
 }
 

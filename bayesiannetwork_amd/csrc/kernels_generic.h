@@ -490,6 +490,54 @@ __global__ void __launch_bounds__(256) ll_partial_listed(const T* __restrict__ a
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// max |c - before| over the real observations of all nodes, and before <- c.  One partial per block.
+template <typename T>
+__global__ void __launch_bounds__(256) normaliser_change_partial(const T* __restrict__ c, T* __restrict__ before,
+                                                                int32_t before_is_zero, int64_t n_nodes, int64_t N,
+                                                                int64_t npad, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double worst = 0.0;
+  const int64_t total = n_nodes * npad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const T now = c[idx];
+    if (idx % npad < N) {
+      const double d = fabs((double)now - (before_is_zero ? 0.0 : (double)before[idx]));
+      worst = d > worst || d != d ? d : worst;  // a NaN is reported, not hidden
+    }
+    before[idx] = now;
+  }
+  red[threadIdx.x] = worst;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) {
+      const double o = red[threadIdx.x + step];
+      if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) max_partials(const double* __restrict__ partial, int32_t count,
+                                                   double* __restrict__ out) {
+  __shared__ double red[256];
+  double worst = 0.0;
+  for (int32_t i = threadIdx.x; i < count; i += 256) {
+    const double o = partial[i];
+    if (o > worst || o != o) worst = o;
+  }
+  red[threadIdx.x] = worst;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) {
+      const double o = red[threadIdx.x + step];
+      if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
 __global__ void __launch_bounds__(256) sum_partials(const double* __restrict__ partial, int32_t count,
                                                    double scale, double* __restrict__ out) {
   __shared__ double red[256];

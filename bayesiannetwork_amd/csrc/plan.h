@@ -103,6 +103,8 @@ struct Plan {
   int64_t n_rows = 0;
   int64_t ones_off = -1;  // arena offset of ones_states * npad elements equal to 1 (never written after creation), or -1
   int32_t ones_states = 0;
+  void* c_before = nullptr;     // snapshot of the normalisers for bn_normaliser_change (allocated on first use)
+  bool c_before_valid = false;  // false: the snapshot counts as all zero
   bool obs_all_pairs = false;  // float plan whose observed nodes all have two states
   bool c_stale = false;        // normalisers are to read as zero (reset since the last iteration)
   int64_t* d_obs_off = nullptr;

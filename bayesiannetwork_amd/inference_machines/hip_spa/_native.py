@@ -69,6 +69,8 @@ def _declare(lib):
     lib.bn_em_statistics.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.bn_m_step.restype = c_int
     lib.bn_m_step.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p]
+    lib.bn_normaliser_change.restype = c_int
+    lib.bn_normaliser_change.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.bn_get_message.restype = c_int
     lib.bn_get_message.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.bn_profile_enable.restype = c_int
@@ -83,7 +85,7 @@ EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
-    "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_m_step", "bn_get_message",
+    "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only",
 )
 

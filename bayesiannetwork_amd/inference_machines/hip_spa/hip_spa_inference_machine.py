@@ -30,6 +30,10 @@ class SpaInferenceMachineSettings(InferenceMachineSettings):
     num_iterations: Optional[int] = None
     allow_loops: bool = False
     callback: Optional[Callable[[int], None]] = None
+    # Not in the reference: stop iterating as soon as no normaliser c[node][n] moved by more than
+    # this between two iterations (``num_iterations`` stays the upper bound).  None = always run
+    # ``num_iterations`` iterations, as the reference does.
+    convergence_tolerance: Optional[float] = None
 
 
 def _stream_handle(device: torch.device) -> int:
@@ -217,6 +221,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
             self.set_cpts([node.cpt for node in self._nodes])
         self.factor_graph = _FactorGraphView(bayesian_network)
         self.must_iterate: bool = True
+        self.iterations_run = 0
         self._evidence_keepalive = None
 
     def __del__(self):
@@ -305,14 +310,34 @@ class HipSpaInferenceMachine(IInferenceMachine):
 
     def _iterate(self) -> None:
         callback = self._settings.callback
-        with torch.cuda.device(self._device):
-            if callback:
-                for iteration in range(self._num_iterations):
-                    _native.check(self._lib.bn_iterate(self._plan, 1, self._stream()))
-                    callback(iteration)
-            else:
-                _native.check(self._lib.bn_iterate(self._plan, self._num_iterations, self._stream()))
+        tolerance = self._settings.convergence_tolerance
+        self.iterations_run = 0
+        # queries made from inside the callback see the state after the iterations run so far
         self.must_iterate = False
+        try:
+            with torch.cuda.device(self._device):
+                if callback or tolerance is not None:
+                    for iteration in range(self._num_iterations):
+                        _native.check(self._lib.bn_iterate(self._plan, 1, self._stream()))
+                        self.iterations_run = iteration + 1
+                        if callback:
+                            callback(iteration)
+                        if tolerance is not None and self.normaliser_change() <= tolerance:
+                            break
+                else:
+                    _native.check(self._lib.bn_iterate(self._plan, self._num_iterations, self._stream()))
+                    self.iterations_run = self._num_iterations
+        except BaseException:
+            self.must_iterate = True
+            raise
+
+    def normaliser_change(self) -> float:
+        """Largest change of any node's local log-likelihood term since this was last asked (since
+        the reset for the first call): the convergence monitor for loopy networks."""
+        out = torch.empty((1,), device=self._device, dtype=torch.float64)
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_normaliser_change(self._plan, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out.item()
 
     def infer_single_nodes(self, nodes: List[Node]) -> List[torch.Tensor]:
         if self.must_iterate:
@@ -351,7 +376,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def log_likelihood_tensor(self) -> torch.Tensor:
         """Log-likelihood as a one-element float64 device tensor (no host sync)."""
         out = torch.empty((1,), device=self._device, dtype=torch.float64)
-        if self.must_iterate and not self._settings.callback:
+        if self.must_iterate and not self._settings.callback and self._settings.convergence_tolerance is None:
             # iterations and log-likelihood in one engine call; the last iteration's messages are
             # completed by the engine if a later query needs them
             with torch.cuda.device(self._device):
@@ -361,6 +386,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
                                                ctypes.c_void_p(out.data_ptr()), None, self._stream())
                 )
             self.must_iterate = False
+            self.iterations_run = self._num_iterations
             return out
         if self.must_iterate:
             self._iterate()
@@ -388,7 +414,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
         When the iterations have not run yet (and no per-iteration callback is set) the last
         iteration is evaluated on the fly for the statistics; message queries made afterwards
         bring the stored messages up to date first, so results are the same either way."""
-        if not self.must_iterate or self._settings.callback:
+        if not self.must_iterate or self._settings.callback or self._settings.convergence_tolerance is not None:
             return self.log_likelihood_tensor(), self.expected_count_sums()
         ll = torch.empty((1,), device=self._device, dtype=torch.float64)
         counts = torch.empty((self._lib.bn_plan_cpt_elements(self._plan),), device=self._device, dtype=torch.float64)
@@ -400,6 +426,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
                                            self._stream())
             )
         self.must_iterate = False
+        self.iterations_run = self._num_iterations
         return ll, counts
 
     def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],

@@ -195,6 +195,17 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
               double regularization, void* new_cpts_dev, void* stream);
 
 /*
+ * Convergence monitor for loopy networks: the largest |c[node][n] - c_before[node][n]| over all
+ * nodes and observations, where c are the normalisers bn_local_log_likelihoods returns and
+ * c_before their values at the previous call of this function on the plan (zero after
+ * bn_reset_messages / creation).  Written as one double to out_dev.  The reference offers no
+ * stopping rule; its loops experiment watches the messages and the sum of the local
+ * log-likelihoods per iteration through the callback (dev_experiments/loops/loops.py:93-120),
+ * which is what this reduces to one number.
+ */
+int bn_normaliser_change(bn_plan* plan, double* out_dev, void* stream);
+
+/*
  * Inspection: copy one message out as [N, S].
  *   owner      node whose factor is one end of the edge
  *   slot       -1 = edge to the owner's own variable, p >= 0 = edge to its p-th parent,

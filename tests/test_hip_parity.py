@@ -175,3 +175,55 @@ def test_errors_mirror_reference():
     machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, [], 0)
     with pytest.raises(Exception, match="0 observed nodes"):
         machine.log_likelihood()
+
+
+@pytest.mark.parametrize("name", ["c4_loops_f64", "c4_loops_f32", "loopy3_f64"])
+def test_iteration_stops_when_the_normalisers_settle_and_callbacks_can_query(name):
+    """convergence_tolerance: same stopping iteration and same answers as the oracle run with the
+    same rule (largest change of any local log-likelihood term, first comparison against zero);
+    and a callback may ask the machine for the log-likelihood after every iteration, as the
+    reference's loops experiment does through the factor graph (dev_experiments/loops/loops.py:93-120)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+    from oracle.spa_oracle import SpaOracle
+
+    fx = Fixture(name)
+    f32 = fx.dtype == torch.float32
+    ts = TorchSettings(device="cuda", dtype=fx.meta["dtype"])
+    network, observed, by_name = fx.build(ts)
+    tolerance, limit = (1e-4, 60) if f32 else (1e-9, 200)
+    seen = []
+    machine = HipSpaInferenceMachine(
+        SpaInferenceMachineSettings(ts, True, num_iterations=limit, allow_loops=True, convergence_tolerance=tolerance,
+                                    callback=lambda it: seen.append(machine.log_likelihood())),
+        network, observed, fx.meta["N"])
+    machine.enter_evidence(Evidence(fx.evidence_tensors(), ts))
+    ll = machine.log_likelihood()
+
+    oracle = SpaOracle(network, observed, fx.meta["N"], dtype=torch.float64, num_iterations=limit, allow_loops=True,
+                       cpts=[n.cpt.detach().cpu().double() for n in network.nodes])
+    oracle.enter_evidence([e.double() for e in fx.evidence_tensors()])
+    before = None
+    want_lls, stopped_at = [], limit
+    for it in range(limit):
+        oracle.iterate_once()
+        oracle.must_iterate = False
+        want_lls.append(oracle.log_likelihood(True))
+        now = torch.stack([oracle.vgroups[g]["c"][k] for g, k in (oracle.v_of[j] for j in range(len(oracle.nodes)))])
+        change = float((now - (before if before is not None else 0.0)).abs().max())
+        before = now.clone()
+        if change <= tolerance:
+            stopped_at = it + 1
+            break
+    assert 1 < stopped_at < limit, "the case is meant to converge inside the limit"
+    if f32:
+        assert abs(machine.iterations_run - stopped_at) <= 1  # the rule is applied to float32 normalisers
+    else:
+        assert machine.iterations_run == stopped_at
+    n = min(len(seen), len(want_lls))
+    np.testing.assert_allclose(seen[:n], want_lls[:n], rtol=4e-5 if f32 else 1e-10)
+    assert ll == seen[-1]
+    for j, node in enumerate(network.nodes):
+        np.testing.assert_allclose(machine.infer_single_nodes([node])[0].cpu().double().numpy(),
+                                   oracle.infer_single(j).numpy(), rtol=2e-4 if f32 else 1e-8, atol=1e-7 if f32 else 0)
