@@ -1,10 +1,11 @@
-// Host side of the specialised float32 path: which groups get which kernel, the scratch
+// Host side of the specialised path (float32; the wide-parent / leaf-family part also float64): which groups get which kernel, the scratch
 // the wide / fused kernels need, and the launches.  Each launch_* helper returns 1 if it
 // handled the group, 0 if the caller must use the generic kernel, and a negative value on
 // a launch failure.
 #pragma once
 
 #include "launch.h"
+#include "kernels_leaf.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -25,6 +26,8 @@ constexpr int32_t kMaxUncovered = 8;
 // observations per lane in the leaf-family kernel: 4 leaves one wave per SIMD, 1 doubles the
 // per-family instruction overhead (both measured slower on the 784-leaf model)
 constexpr int32_t kLeafVec = 2;
+// waves a leaf-family launch needs per tile (a wave covers 64 * kLeafVec observations)
+inline int32_t leaf_parts(const Plan& p) { return p.tile / (64 * kLeafVec); }
 
 struct WideNode {
   int32_t node = -1, vgroup = -1, vpos = -1;
@@ -43,11 +46,11 @@ struct WideNode {
 struct FusedFamily {
   int32_t wide_index = -1;
   int32_t wide_index2 = -1;     // second wide parent of two-parent families, else -1
-  float* m_state = nullptr;     // [K][D0 + D1][npad] two-parent loop state (previous messages to the parents)
+  void* m_state = nullptr;      // [K][D0 + D1][npad] of the plan's element type: two-parent loop state (previous messages to the parents)
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
-  float* z_state = nullptr;     // [K][npad] loop-state normalisers
-  float* em_partial = nullptr;  // [K][entries][slots], written by the reduce-mode kernel
+  void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
+  void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
   int32_t slots = 0;
   double* ll_part = nullptr;    // [chunks][npad], written by the reduce-mode kernel
   int32_t ll_rows = 0;
@@ -67,6 +70,7 @@ struct FastState {
   std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
   std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
   std::vector<char> vgroup_skip;              // variable groups whose every node a fused kernel serves
+  std::vector<char> vgroup_wide;              // variable groups served by the wide-node path
   // parentless factor groups whose output (the prior, broadcast over observations) is already in
   // place: it only changes with the CPTs
   std::vector<char> root_written;
@@ -87,7 +91,7 @@ inline bool small_dim(int32_t d) {
 }
 
 inline bool is_wide_group(const Plan& p, const VariableGroup& g) {
-  return p.dtype == 0 && g.num_inputs > kWideFanIn && small_dim(g.num_states);
+  return g.num_inputs > kWideFanIn && small_dim(g.num_states);
 }
 
 template <typename U>
@@ -143,7 +147,6 @@ inline int prepare_fast(Plan& p) {
   FastState& st = *fast_state(p);
   st.vgroup_skip.assign(p.vgroups.size(), 0);
   st.root_written.assign(p.fgroups.size(), 0);
-  if (p.dtype != 0) return 0;
   // wide variable nodes
   for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
     const VariableGroup& g = p.vgroups[gi];
@@ -205,17 +208,54 @@ inline int prepare_fast(Plan& p) {
       handled[j] = 1;
     }
     if (!dev_upload(obs, &fam.d_obs_off, p.device_bytes) || !dev_upload(cs, &fam.d_c_off, p.device_bytes)) return -2;
-    fam.slots = (int32_t)(p.ntiles * (4 / kLeafVec));
+    fam.slots = (int32_t)(p.ntiles * leaf_parts(p));
     const size_t em_elems = g.nodes.size() * (size_t)g.cpt_elems * fam.slots;
-    if (hipMalloc(reinterpret_cast<void**>(&fam.em_partial), em_elems * sizeof(float)) != hipSuccess) return -2;
-    p.device_bytes += (int64_t)(em_elems * sizeof(float));
-    if (hipMalloc(reinterpret_cast<void**>(&fam.z_state), g.nodes.size() * (size_t)p.npad * sizeof(float)) != hipSuccess)
+    if (hipMalloc(reinterpret_cast<void**>(&fam.em_partial), em_elems * (size_t)p.elem_size) != hipSuccess) return -2;
+    p.device_bytes += (int64_t)(em_elems * (size_t)p.elem_size);
+    if (hipMalloc(reinterpret_cast<void**>(&fam.z_state), g.nodes.size() * (size_t)p.npad * (size_t)p.elem_size) != hipSuccess)
       return -2;
-    p.device_bytes += (int64_t)(g.nodes.size() * (size_t)p.npad * sizeof(float));
+    p.device_bytes += (int64_t)(g.nodes.size() * (size_t)p.npad * (size_t)p.elem_size);
     if (num_parents == 2) {
       const size_t m_elems = g.nodes.size() * (size_t)(g.dims[0] + g.dims[1]) * p.npad;
-      if (hipMalloc(reinterpret_cast<void**>(&fam.m_state), m_elems * sizeof(float)) != hipSuccess) return -2;
-      p.device_bytes += (int64_t)(m_elems * sizeof(float));
+      if (hipMalloc(reinterpret_cast<void**>(&fam.m_state), m_elems * (size_t)p.elem_size) != hipSuccess) return -2;
+      p.device_bytes += (int64_t)(m_elems * (size_t)p.elem_size);
+    }
+  }
+  // The standalone wide kernels (product / emission) exist for float32 only: a float64 plan takes
+  // the wide path for a variable group only if a leaf-family kernel serves every node of it, and
+  // gives up the fusion of the others (their groups then run on the generic kernels).
+  st.vgroup_wide.assign(p.vgroups.size(), 0);
+  auto unfuse = [&](int32_t fi) {
+    auto it = st.fused.find(fi);
+    if (it == st.fused.end()) return;
+    FusedFamily& fam = it->second;
+    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, fam.em_partial, fam.z_state, fam.m_state})
+      if (buffer) (void)hipFree(buffer);
+    for (int32_t j : p.fgroups[fi].nodes) handled[j] = 0;
+    for (int32_t widx : {fam.wide_index, fam.wide_index2}) {
+      if (widx < 0) continue;
+      st.wide[widx].fused_fgroup = -1;
+      st.wide[widx].covered.clear();
+      st.wide[widx].uncovered.clear();
+    }
+    st.fused.erase(it);
+  };
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
+      const VariableGroup& g = p.vgroups[gi];
+      if (!is_wide_group(p, g)) continue;
+      size_t fused_nodes = 0;
+      for (int32_t j : g.nodes) fused_nodes += st.wide[st.wide_of_node[j]].fused_fgroup >= 0 ? 1 : 0;
+      st.vgroup_wide[gi] = (p.dtype == 0 || fused_nodes == g.nodes.size()) ? 1 : 0;
+      if (st.vgroup_wide[gi] || fused_nodes == 0) continue;
+      for (int32_t j : g.nodes) {
+        const int32_t fi = st.wide[st.wide_of_node[j]].fused_fgroup;
+        if (fi >= 0) {
+          unfuse(fi);
+          changed = true;
+        }
+      }
     }
   }
   for (size_t gi = 0; gi < p.vgroups.size(); ++gi) {
@@ -232,6 +272,7 @@ inline int prepare_fast(Plan& p) {
   }
   // chunk geometry + scratch
   for (auto& w : st.wide) {
+    if (p.dtype != 0 && w.fused_fgroup < 0) continue;  // not on the wide path in a float64 plan
     if (w.fused_fgroup < 0) {
       for (int32_t i = 0; i < w.I - 2; ++i) w.covered.push_back(i);
       w.uncovered = {w.I - 2, w.I - 1};
@@ -240,7 +281,7 @@ inline int prepare_fast(Plan& p) {
     // one round of resident waves (4 per SIMD x 1024 SIMDs) per launch, never a partly filled
     // second one: measured best on the 784-leaf model (8 chunks at 60 000 observations; 7 and 9
     // are both 5 % slower, 13 and more pay in the combine)
-    int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * (4 / kLeafVec)));
+    int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * leaf_parts(p)));
     // small batches cannot fill the chip anyway; there the combine sets the limit: its waves
     // each walk a share of the chunks, three groups of four at most
     want = std::min<int64_t>(want, 4 * kCombineMaxWaves * 3);
@@ -296,25 +337,33 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   return a;
 }
 
-template <int S>
-inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, float* arena, int32_t fresh,
+template <typename T, int S>
+inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, T* arena, int32_t fresh,
                              hipStream_t s) {
   const WideArgs a = wide_args(p, g, w, fresh);
   const bool fused = w.fused_fgroup >= 0;
   if (!fresh && (!fused || !w.partials_valid)) {
-    launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
-    if (!launch_ok()) return false;
+    if constexpr (std::is_same<T, float>::value) {
+      launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+      if (!launch_ok()) return false;
+    } else {
+      return false;  // float64 wide nodes are always fused, and their kernel keeps the partials valid
+    }
   }
   {
     // waves per block: one per group of four chunks, none to spare while the messages are fresh
     const int32_t nw = fresh ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
-    launch(wide_combine_fast<S>, dim3((uint32_t)(p.ntiles * (kTile / 64))), dim3(64 * nw), combine_lds_bytes<S>(nw), s,
-           arena, a);
+    launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw),
+           combine_lds_bytes<S>(nw), s, arena, a);
   }
   if (!launch_ok()) return false;
   if (!fused) {
-    launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
-    if (!launch_ok()) return false;
+    if constexpr (std::is_same<T, float>::value) {
+      launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+      if (!launch_ok()) return false;
+    } else {
+      return false;
+    }
   }
   return true;
 }
@@ -323,7 +372,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
 // serves it (profiling only).  Returns false when the defaults apply.
 inline bool variable_profile(const Plan& p, size_t gi, std::string& label, double& bytes) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0) return false;
+  if (!st) return false;
   const VariableGroup& g = p.vgroups[gi];
   if (st->vgroup_skip[gi]) {
     label = "variable_pass(fused into leaf_family)[I=" + std::to_string(g.num_inputs) + ",S=" +
@@ -331,7 +380,7 @@ inline bool variable_profile(const Plan& p, size_t gi, std::string& label, doubl
     bytes = 0;
     return true;
   }
-  if (!is_wide_group(p, g)) return false;
+  if (!st->vgroup_wide[gi]) return false;
   bool any_fused = false;
   double fused_bytes = 0;
   for (int32_t j : g.nodes) {
@@ -349,7 +398,7 @@ inline bool variable_profile(const Plan& p, size_t gi, std::string& label, doubl
 
 inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double& bytes) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0) return false;
+  if (!st) return false;
   auto it = st->fused.find((int32_t)fi);
   if (it == st->fused.end()) return false;
   const FactorGroup& g = p.fgroups[fi];
@@ -375,30 +424,30 @@ inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double&
 
 template <typename T>
 int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, hipStream_t s) {
+  FastState* st = fast_state(p);
+  const size_t gi = (size_t)(&g - p.vgroups.data());
+  if (st && st->vgroup_skip[gi]) return 1;  // done inside the leaf-family kernel
+  if (st && st->vgroup_wide[gi]) {
+    for (int32_t j : g.nodes) {
+      WideNode& w = st->wide[st->wide_of_node[j]];
+      bool ok = false;
+      switch (g.num_states) {
+#define X(SV)                                                   \
+  case SV:                                                      \
+    ok = launch_wide_node<T, SV>(p, g, w, arena_t, fresh, s);   \
+    break;
+        BN_SMALL_DIMS(X)
+#undef X
+      }
+      if (!ok) return -1;
+    }
+    return 1;
+  }
   if constexpr (!std::is_same<T, float>::value) {
     return 0;
   } else {
     float* arena = arena_t;
-    FastState* st = fast_state(p);
-    const size_t gi = (size_t)(&g - p.vgroups.data());
     const int32_t K = (int32_t)g.nodes.size();
-    if (st && st->vgroup_skip[gi]) return 1;  // done inside the leaf-family kernel
-    if (st && is_wide_group(p, g)) {
-      for (int32_t j : g.nodes) {
-        WideNode& w = st->wide[st->wide_of_node[j]];
-        bool ok = false;
-        switch (g.num_states) {
-#define X(SV)                                                \
-  case SV:                                                   \
-    ok = launch_wide_node<SV>(p, g, w, arena, fresh, s);     \
-    break;
-          BN_SMALL_DIMS(X)
-#undef X
-        }
-        if (!ok) return -1;
-      }
-      return 1;
-    }
     if (g.num_inputs > 4) return 0;
     VarSmallFn fn = g.num_inputs * g.num_states <= 12 ? var_small_lookup(g.num_inputs, g.num_states) : nullptr;
     if (fn) {
@@ -448,27 +497,27 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
   }
 }
 
-using LeafFamilyFn = void (*)(float*, const float*, LeafFamilyArgs);
+template <typename T>
+using LeafFamilyFn = void (*)(T*, const T*, LeafFamilyArgs<T>);
 
-
-template <int D0, int MODE>
-inline LeafFamilyFn leaf_family_for_s(int32_t s) {
+template <typename T, int D0, int MODE>
+inline LeafFamilyFn<T> leaf_family_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return leaf_family_p1<D0, SV, kLeafVec, MODE>;
+    return leaf_family_p1<T, D0, SV, kLeafVec, MODE>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-template <int MODE>
-inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return leaf_family_for_s<DV, MODE>(s);
+    return leaf_family_for_s<T, DV, MODE>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
@@ -476,22 +525,23 @@ inline LeafFamilyFn leaf_family_lookup(int32_t d0, int32_t s) {
 }
 
 // w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
-inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, float* arena,
-                              const float* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
+template <typename T>
+inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena,
+                              const T* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
                               bool with_counts = true) {
   const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
-  LeafFamilyFn fn = nullptr;
+  LeafFamilyFn<T> fn = nullptr;
   switch (mode + 3 * state) {
-#define X(M)                                                                                        \
-  case M:                                                                                           \
-    fn = w2 ? leaf_family_p2<2, 2, 2, kLeafVec, M> : leaf_family_lookup<M>(g.dims[0], g.dims[1]);   \
+#define X(M)                                                                                                    \
+  case M:                                                                                                       \
+    fn = w2 ? leaf_family_p2<T, 2, 2, 2, kLeafVec, M> : leaf_family_lookup<T, M>(g.dims[0], g.dims[1]);         \
     break;
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
   }
   if (!fn) return -1;
   if (w2 && (w2->chunks != w.chunks || w2->chunk_len != w.chunk_len)) return -1;
-  LeafFamilyArgs a;
+  LeafFamilyArgs<T> a;
   a.f_in = g.d_in;
   a.f_out = g.d_out;
   a.cpt_off = g.d_cpt;
@@ -506,15 +556,15 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.npad = p.npad;
   a.ntiles = p.ntiles;
   a.N = p.N;
-  a.z_state = fam.z_state;
-  a.em_partial = with_counts ? fam.em_partial : nullptr;
+  a.z_state = static_cast<T*>(fam.z_state);
+  a.em_partial = with_counts ? static_cast<T*>(fam.em_partial) : nullptr;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
   a.part_mant2 = w2 ? w2->part_mant : nullptr;
   a.part_exp2 = w2 ? w2->part_exp : nullptr;
   a.scaled2 = w2 ? w2->scaled : nullptr;
-  a.m_state = fam.m_state;
-  launch(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * (4 / kLeafVec))), dim3(256), 0, s, arena, cpts, a);
+  a.m_state = static_cast<T*>(fam.m_state);
+  launch(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
     fam.pending = true;
@@ -534,14 +584,19 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
 // anything that reads or changes messages, evidence or CPTs.
 inline int complete_pending_fast(Plan& p, hipStream_t s) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0) return 0;
+  if (!st) return 0;
   for (auto& kv : st->fused) {
     FusedFamily& fam = kv.second;
     if (!fam.pending) continue;
     FactorGroup& g = p.fgroups[kv.first];
-    int rc = launch_leaf_family(p, g, fam, st->wide[fam.wide_index],
-                                fam.wide_index2 >= 0 ? &st->wide[fam.wide_index2] : nullptr, static_cast<float*>(p.arena),
-                                static_cast<const float*>(p.cpts), fam.pending_fresh, fam.pending_first, kLeafFull, s);
+    WideNode* w2 = fam.wide_index2 >= 0 ? &st->wide[fam.wide_index2] : nullptr;
+    const int rc = p.dtype == 0
+                       ? launch_leaf_family<float>(p, g, fam, st->wide[fam.wide_index], w2, static_cast<float*>(p.arena),
+                                                   static_cast<const float*>(p.cpts), fam.pending_fresh,
+                                                   fam.pending_first, kLeafFull, s)
+                       : launch_leaf_family<double>(p, g, fam, st->wide[fam.wide_index], w2,
+                                                    static_cast<double*>(p.arena), static_cast<const double*>(p.cpts),
+                                                    fam.pending_fresh, fam.pending_first, kLeafFull, s);
     if (rc < 0) return rc;
   }
   return 0;
@@ -549,7 +604,7 @@ inline int complete_pending_fast(Plan& p, hipStream_t s) {
 
 inline bool em_is_reduced(const Plan& p, size_t fi) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0) return false;
+  if (!st) return false;
   auto it = st->fused.find((int32_t)fi);
   return it != st->fused.end() && it->second.em_ready;
 }
@@ -559,7 +614,7 @@ inline bool em_is_reduced(const Plan& p, size_t fi) {
 // plan is not in that state, -1 on a launch failure.
 inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hipStream_t s) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0 || st->fused.empty()) return 0;
+  if (!st || st->fused.empty()) return 0;
   for (auto& kv : st->fused)
     if (!kv.second.pending) return 0;
   int32_t used = 0;
@@ -570,8 +625,13 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
     const int64_t rows = n_listed + fam.ll_rows;
     const int32_t blocks = (int32_t)std::min<int64_t>(max_blocks - used, rows * ((p.npad + 255) / 256));
     if (blocks <= 0) return -1;
-    launch(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
-                       st->d_ll_offs, n_listed, fam.ll_part, (int64_t)fam.ll_rows, p.N, p.npad, partial + used);
+    if (p.dtype == 0) {
+      launch(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),
+             st->d_ll_offs, n_listed, fam.ll_part, (int64_t)fam.ll_rows, p.N, p.npad, partial + used);
+    } else {
+      launch(ll_partial_listed<double>, dim3(blocks), dim3(256), 0, s, static_cast<const double*>(p.arena),
+             st->d_ll_offs, n_listed, fam.ll_part, (int64_t)fam.ll_rows, p.N, p.npad, partial + used);
+    }
     if (!launch_ok()) return -1;
     used += blocks;
     listed_done = true;
@@ -582,14 +642,20 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
 // EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.
 inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
   FastState* st = fast_state(p);
-  if (!st || p.dtype != 0) return 0;
+  if (!st) return 0;
   auto it = st->fused.find((int32_t)fi);
   if (it == st->fused.end() || !it->second.em_ready) return 0;
   FactorGroup& g = p.fgroups[fi];
   const int64_t items = (int64_t)g.nodes.size() * g.cpt_elems;
-  launch(em_finalize_slots, dim3(wave_blocks(items)), dim3(256), 0, s, it->second.em_partial,
-                     static_cast<const float*>(p.cpts), g.d_cpt, (int32_t)g.nodes.size(), (int32_t)g.cpt_elems,
-                     it->second.slots, accum);
+  if (p.dtype == 0) {
+    launch(em_finalize_slots<float>, dim3(wave_blocks(items)), dim3(256), 0, s,
+           static_cast<const float*>(it->second.em_partial), static_cast<const float*>(p.cpts), g.d_cpt,
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots, accum);
+  } else {
+    launch(em_finalize_slots<double>, dim3(wave_blocks(items)), dim3(256), 0, s,
+           static_cast<const double*>(it->second.em_partial), static_cast<const double*>(p.cpts), g.d_cpt,
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots, accum);
+  }
   return launch_ok() ? 1 : -1;
 }
 
@@ -597,6 +663,19 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
 template <typename T>
 int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t first_iteration,
                        int32_t last_iteration, int32_t reduce_last, hipStream_t s) {
+  FastState* st = fast_state(p);
+  const size_t fi = (size_t)(&g - p.fgroups.data());
+  if (st) {
+    auto it = st->fused.find((int32_t)fi);
+    if (it != st->fused.end()) {
+      WideNode& w = st->wide[it->second.wide_index];
+      const int32_t mode = !last_iteration ? kLeafLoop : (reduce_last ? kLeafReduce : kLeafFull);
+      WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
+      // reduce_last == 2: only the log-likelihood sums are wanted from the reduce-mode launch
+      return launch_leaf_family<T>(p, g, it->second, w, w2, arena_t, cpts_t, fresh, first_iteration, mode, s,
+                                   reduce_last != 2);
+    }
+  }
   if constexpr (!std::is_same<T, float>::value) {
     return 0;
   } else {
@@ -604,19 +683,6 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
     const float* cpts = cpts_t;
     const int32_t K = (int32_t)g.nodes.size();
     const uint32_t blocks = wave_blocks((int64_t)K * p.ntiles);
-    FastState* st = fast_state(p);
-    const size_t fi = (size_t)(&g - p.fgroups.data());
-    if (st) {
-      auto it = st->fused.find((int32_t)fi);
-      if (it != st->fused.end()) {
-        WideNode& w = st->wide[it->second.wide_index];
-        const int32_t mode = !last_iteration ? kLeafLoop : (reduce_last ? kLeafReduce : kLeafFull);
-        WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
-        // reduce_last == 2: only the log-likelihood sums are wanted from the reduce-mode launch
-        return launch_leaf_family(p, g, it->second, w, w2, arena, cpts, fresh, first_iteration, mode, s,
-                                  reduce_last != 2);
-      }
-    }
     if (g.dims.size() == 1) {
       if (st && st->root_written[fi]) return 1;
       launch(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],

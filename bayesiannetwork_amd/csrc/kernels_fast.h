@@ -21,6 +21,11 @@
 namespace bn {
 
 constexpr int32_t kTile = 256;       // float32 tile: 64 lanes x 4 observations
+// observations per tile for a plan of element type T (a message row is 1 KiB either way)
+template <typename T>
+struct tile_of {
+  static constexpr int32_t value = sizeof(T) == 4 ? 256 : 128;
+};
 constexpr int32_t kWavesPerBlock = 4;
 constexpr int32_t kWideFanIn = 24;   // variable nodes with more inputs take the chunked path
 constexpr int32_t kWideMaxStates = 16;
