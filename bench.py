@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]): Q(10) -> 784 x Y(2), random CPTs (seed 0), synthetic
+Workload (the latent-class model of the reference's dev_experiments/mnist, single-hidden-node
+form): Q(10) -> 784 x Y(2), random CPTs (seed 0), synthetic
 evidence x ~ Bernoulli(0.2) soft-clamped to [5e-7, 1-5e-7] (seed 1 + rank), float32.
 One step = one EM step of the mini-batch optimizer on one batch per GPU: fresh machine
 (pooled plan), enter_evidence, T=4 flooding iterations, log-likelihood, expected counts,
@@ -11,7 +12,10 @@ One step = one EM step of the mini-batch optimizer on one batch per GPU: fresh m
 resident in HBM before the timed region.  Weak scaling: every rank gets its own batch of
 --batch observations; value = all ranks' observations / slowest rank's time.
 
-Rank 0 prints one JSON line (see README / DESIGN.md for the fields).
+Rank 0 prints one JSON line: metric / value / unit, the step time, the workload in `config`,
+`roofline` for the dominant kernel (algorithmic bytes per launch / measured launch time against the
+HBM peak, plus the profiler-measured HBM bytes per launch in `traffic`), per-kernel durations in
+`kernels`, and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
 """
 
 from __future__ import annotations
@@ -81,7 +85,7 @@ def build_model(ts, model: str, num_pixels: int = 784):
 
 
 def build_deep_tree(ts, depth: int = 6, states: int = 64):
-    """BASELINE.json configs[4]: balanced binary tree of 64-state hidden nodes (2^depth - 1 of
+    """Deep-tree workload: balanced binary tree of 64-state hidden nodes (2^depth - 1 of
     them) with one observed 64-state leaf under every hidden leaf; CPTs [64] / [64, 64]."""
     from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
 
