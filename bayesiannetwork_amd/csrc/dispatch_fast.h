@@ -32,11 +32,13 @@ inline int32_t leaf_parts(const Plan& p) { return p.tile / (64 * kLeafVec); }
 struct WideNode {
   int32_t node = -1, vgroup = -1, vpos = -1;
   int32_t S = 0, I = 0;
-  int32_t fused_fgroup = -1;  // factor group whose leaf-family kernel maintains the partials, or -1
+  int32_t fused_fgroup = -1;  // first factor group whose leaf-family kernel maintains partials of this node, or -1
+  std::vector<int32_t> fused_fgroups;  // all of them, in the order their families appear in `covered`
   int32_t chunks = 0, chunk_len = 0;
   std::vector<int32_t> covered, uncovered;
   int32_t* d_covered = nullptr;
   int32_t* d_uncovered = nullptr;
+  int32_t* d_chunk_first = nullptr;  // [chunks + 1] chunk boundaries in `covered`
   double* part_mant = nullptr;
   int32_t* part_exp = nullptr;
   double* scaled = nullptr;
@@ -46,6 +48,7 @@ struct WideNode {
 struct FusedFamily {
   int32_t wide_index = -1;
   int32_t wide_index2 = -1;     // second wide parent of two-parent families, else -1
+  int32_t chunk_base = 0, chunks = 0, chunk_len = 0;  // this group's range of the parent's chunk partials
   void* m_state = nullptr;      // [K][D0 + D1][npad] of the plan's element type: two-parent loop state (previous messages to the parents)
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
@@ -109,6 +112,7 @@ inline void release_fast(Plan& p) {
   for (auto& w : st->wide) {
     if (w.d_covered) (void)hipFree(w.d_covered);
     if (w.d_uncovered) (void)hipFree(w.d_uncovered);
+    if (w.d_chunk_first) (void)hipFree(w.d_chunk_first);
     if (w.part_mant) (void)hipFree(w.part_mant);
     if (w.part_exp) (void)hipFree(w.part_exp);
     if (w.scaled) (void)hipFree(w.scaled);
@@ -162,8 +166,14 @@ inline int prepare_fast(Plan& p) {
       st.wide.push_back(std::move(w));
     }
   }
-  // leaf families around one or two wide parents
+  // Leaf families around one or two wide parents.  A wide node can carry several one-parent family
+  // groups (children of different cardinalities), each with its own range of chunks; a two-parent
+  // group has both its parents to itself.
   std::vector<char> handled(p.n_nodes, 0);
+  struct Candidate {
+    int32_t fi, num_parents, widx[2];
+  };
+  std::vector<Candidate> candidates;
   for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
     const FactorGroup& g = p.fgroups[fi];
     const int32_t num_parents = (int32_t)g.dims.size() - 1;
@@ -173,34 +183,59 @@ inline int prepare_fast(Plan& p) {
       continue;
     }
     const std::vector<int32_t>& family_parents = p.parents[g.nodes[0]];
-    int32_t widx[2] = {-1, -1};
+    Candidate c{(int32_t)fi, num_parents, {-1, -1}};
     bool ok = g.nodes.size() >= 16;
     for (int32_t q = 0; q < num_parents && ok; ++q) {
       auto wit = st.wide_of_node.find(family_parents[q]);
-      ok = wit != st.wide_of_node.end() && st.wide[wit->second].fused_fgroup < 0 &&
-           st.wide[wit->second].I - (int32_t)g.nodes.size() <= kMaxUncovered;
-      if (ok) widx[q] = wit->second;
+      ok = wit != st.wide_of_node.end();
+      if (ok) c.widx[q] = wit->second;
     }
-    ok = ok && (num_parents == 1 || widx[0] != widx[1]);
+    ok = ok && (num_parents == 1 || c.widx[0] != c.widx[1]);
     for (int32_t j : g.nodes) ok = ok && p.parents[j] == family_parents && p.children[j].empty();
+    if (ok) candidates.push_back(c);
+  }
+  std::vector<char> accepted(p.fgroups.size(), 0), exclusive(st.wide.size(), 0);
+  for (const Candidate& c : candidates) {
+    if (c.num_parents != 2) continue;
+    const int32_t K = (int32_t)p.fgroups[c.fi].nodes.size();
+    bool ok = true;
+    for (int32_t q = 0; q < 2; ++q) ok = ok && !exclusive[c.widx[q]] && st.wide[c.widx[q]].I - K <= kMaxUncovered;
     if (!ok) continue;
-    // covered slots of each parent, in the factor group's node order
-    for (int32_t q = 0; q < num_parents; ++q) {
-      WideNode& w = st.wide[widx[q]];
-      std::vector<char> is_covered(w.I, 0);
-      const auto& ch = p.children[family_parents[q]];
-      for (int32_t j : g.nodes) {
-        const int32_t slot = (int32_t)(std::find(ch.begin(), ch.end(), j) - ch.begin());
-        w.covered.push_back(slot);
-        is_covered[slot] = 1;
-      }
-      for (int32_t i = 0; i < w.I; ++i)
-        if (!is_covered[i]) w.uncovered.push_back(i);
-      w.fused_fgroup = (int32_t)fi;
+    accepted[c.fi] = 1;
+    exclusive[c.widx[0]] = exclusive[c.widx[1]] = 1;
+  }
+  for (size_t wi = 0; wi < st.wide.size(); ++wi) {
+    if (exclusive[wi]) continue;
+    int32_t total = 0, largest = -1;
+    for (const Candidate& c : candidates) {
+      if (c.num_parents != 1 || c.widx[0] != (int32_t)wi) continue;
+      const int32_t K = (int32_t)p.fgroups[c.fi].nodes.size();
+      total += K;
+      if (largest < 0 || K > (int32_t)p.fgroups[largest].nodes.size()) largest = c.fi;
     }
-    FusedFamily& fam = st.fused[(int32_t)fi];  // in place: release_fast frees it whatever happens below
-    fam.wide_index = widx[0];
-    fam.wide_index2 = widx[1];
+    if (largest < 0) continue;
+    if (st.wide[wi].I - total <= kMaxUncovered) {
+      for (const Candidate& c : candidates)
+        if (c.num_parents == 1 && c.widx[0] == (int32_t)wi) accepted[c.fi] = 1;
+    } else if (st.wide[wi].I - (int32_t)p.fgroups[largest].nodes.size() <= kMaxUncovered) {
+      accepted[largest] = 1;
+    }
+  }
+  for (const Candidate& c : candidates) {
+    if (!accepted[c.fi]) continue;
+    const FactorGroup& g = p.fgroups[c.fi];
+    const std::vector<int32_t>& family_parents = p.parents[g.nodes[0]];
+    // covered slots of each parent, in the factor group's node order
+    for (int32_t q = 0; q < c.num_parents; ++q) {
+      WideNode& w = st.wide[c.widx[q]];
+      const auto& ch = p.children[family_parents[q]];
+      for (int32_t j : g.nodes) w.covered.push_back((int32_t)(std::find(ch.begin(), ch.end(), j) - ch.begin()));
+      w.fused_fgroups.push_back(c.fi);
+      if (w.fused_fgroup < 0) w.fused_fgroup = c.fi;
+    }
+    FusedFamily& fam = st.fused[c.fi];  // in place: release_fast frees it whatever happens below
+    fam.wide_index = c.widx[0];
+    fam.wide_index2 = c.widx[1];
     std::vector<int64_t> obs, cs;
     for (int32_t j : g.nodes) {
       obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : p.ones_off);
@@ -215,7 +250,7 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&fam.z_state), g.nodes.size() * (size_t)p.npad * (size_t)p.elem_size) != hipSuccess)
       return -2;
     p.device_bytes += (int64_t)(g.nodes.size() * (size_t)p.npad * (size_t)p.elem_size);
-    if (num_parents == 2) {
+    if (c.num_parents == 2) {
       const size_t m_elems = g.nodes.size() * (size_t)(g.dims[0] + g.dims[1]) * p.npad;
       if (hipMalloc(reinterpret_cast<void**>(&fam.m_state), m_elems * (size_t)p.elem_size) != hipSuccess) return -2;
       p.device_bytes += (int64_t)(m_elems * (size_t)p.elem_size);
@@ -235,8 +270,8 @@ inline int prepare_fast(Plan& p) {
     for (int32_t widx : {fam.wide_index, fam.wide_index2}) {
       if (widx < 0) continue;
       st.wide[widx].fused_fgroup = -1;
+      st.wide[widx].fused_fgroups.clear();
       st.wide[widx].covered.clear();
-      st.wide[widx].uncovered.clear();
     }
     st.fused.erase(it);
   };
@@ -250,8 +285,8 @@ inline int prepare_fast(Plan& p) {
       st.vgroup_wide[gi] = (p.dtype == 0 || fused_nodes == g.nodes.size()) ? 1 : 0;
       if (st.vgroup_wide[gi] || fused_nodes == 0) continue;
       for (int32_t j : g.nodes) {
-        const int32_t fi = st.wide[st.wide_of_node[j]].fused_fgroup;
-        if (fi >= 0) {
+        const std::vector<int32_t> groups = st.wide[st.wide_of_node[j]].fused_fgroups;  // copy: unfuse edits it
+        for (int32_t fi : groups) {
           unfuse(fi);
           changed = true;
         }
@@ -276,6 +311,12 @@ inline int prepare_fast(Plan& p) {
     if (w.fused_fgroup < 0) {
       for (int32_t i = 0; i < w.I - 2; ++i) w.covered.push_back(i);
       w.uncovered = {w.I - 2, w.I - 1};
+    } else {
+      std::vector<char> is_covered(w.I, 0);
+      for (int32_t slot : w.covered) is_covered[slot] = 1;
+      w.uncovered.clear();
+      for (int32_t i = 0; i < w.I; ++i)
+        if (!is_covered[i]) w.uncovered.push_back(i);
     }
     const int32_t n = (int32_t)w.covered.size();
     // one round of resident waves (4 per SIMD x 1024 SIMDs) per launch, never a partly filled
@@ -291,6 +332,26 @@ inline int prepare_fast(Plan& p) {
     if (w.fused_fgroup >= 0) chunks = std::max(chunks, (n + kLeafMaxChunkLen - 1) / kLeafMaxChunkLen);
     w.chunk_len = (n + chunks - 1) / chunks;
     w.chunks = (n + w.chunk_len - 1) / w.chunk_len;
+    std::vector<int32_t> chunk_first;
+    if (w.fused_fgroup >= 0) {
+      // every fused group gets whole chunks of its own, one group after the other
+      w.chunks = 0;
+      int32_t group_first = 0;
+      for (int32_t fi : w.fused_fgroups) {
+        FusedFamily& fam = st.fused[fi];
+        const int32_t members = (int32_t)p.fgroups[fi].nodes.size();
+        fam.chunk_len = w.chunk_len;
+        fam.chunks = (members + w.chunk_len - 1) / w.chunk_len;
+        fam.chunk_base = w.chunks;
+        for (int32_t c = 0; c < fam.chunks; ++c) chunk_first.push_back(group_first + c * w.chunk_len);
+        w.chunks += fam.chunks;
+        group_first += members;
+      }
+    } else {
+      for (int32_t c = 0; c < w.chunks; ++c) chunk_first.push_back(c * w.chunk_len);
+    }
+    chunk_first.push_back(n);
+    if (!dev_upload(chunk_first, &w.d_chunk_first, p.device_bytes)) return -2;
     if (!dev_upload(w.covered, &w.d_covered, p.device_bytes) || !dev_upload(w.uncovered, &w.d_uncovered, p.device_bytes))
       return -2;
     const size_t rows = (size_t)w.chunks * w.S * p.npad;
@@ -298,12 +359,13 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), rows * sizeof(int32_t)) != hipSuccess) return -2;
     if (hipMalloc(reinterpret_cast<void**>(&w.scaled), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
     p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 8);
-    if (w.fused_fgroup >= 0 && !st.fused[w.fused_fgroup].ll_part) {
-      FusedFamily& fam = st.fused[w.fused_fgroup];
-      fam.ll_rows = w.chunks;
-      if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)w.chunks * p.npad * sizeof(double)) != hipSuccess)
+    for (int32_t fi : w.fused_fgroups) {
+      FusedFamily& fam = st.fused[fi];
+      if (fam.ll_part) continue;  // a two-parent group is visited from both its parents
+      fam.ll_rows = fam.chunks;
+      if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.chunks * p.npad * sizeof(double)) != hipSuccess)
         return -2;
-      p.device_bytes += (int64_t)((size_t)w.chunks * p.npad * sizeof(double));
+      p.device_bytes += (int64_t)((size_t)fam.chunks * p.npad * sizeof(double));
     }
   }
   return 0;
@@ -319,6 +381,7 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   a.chunk_len = w.chunk_len;
   a.n_covered = (int32_t)w.covered.size();
   a.covered = w.d_covered;
+  a.chunk_first = w.d_chunk_first;
   a.uncovered = w.d_uncovered;
   a.n_uncovered = (int32_t)w.uncovered.size();
   a.part_mant = w.part_mant;
@@ -347,7 +410,9 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
       launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
       if (!launch_ok()) return false;
     } else {
-      return false;  // float64 wide nodes are always fused, and their kernel keeps the partials valid
+      launch(wide_product_any<T, S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s,
+             arena, a);
+      if (!launch_ok()) return false;
     }
   }
   {
@@ -410,11 +475,11 @@ inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double&
     const int32_t fan_in = 1 + (p.observed_slot_of[j] >= 0 ? 1 : 0);
     leaf += (double)p.states[j] * fan_in + (double)p.states[j] + 1;
   }
-  bytes += 2.0 * w.S * (double)w.covered.size() * (double)p.N * (double)p.elem_size +
+  bytes += 2.0 * w.S * (double)g.nodes.size() * (double)p.N * (double)p.elem_size +
            leaf * (double)p.N * (double)p.elem_size;
   if (it->second.wide_index2 >= 0) {
     const WideNode& w2 = st->wide[it->second.wide_index2];
-    bytes += 2.0 * w2.S * (double)w2.covered.size() * (double)p.N * (double)p.elem_size;
+    bytes += 2.0 * w2.S * (double)g.nodes.size() * (double)p.N * (double)p.elem_size;
   }
   label = "leaf_family[";
   for (size_t d = 0; d < g.dims.size(); ++d) label += (d ? "x" : "") + std::to_string(g.dims[d]);
@@ -540,7 +605,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
 #undef X
   }
   if (!fn) return -1;
-  if (w2 && (w2->chunks != w.chunks || w2->chunk_len != w.chunk_len)) return -1;
+  if (w2 && (w2->chunks != fam.chunks || w.chunks != fam.chunks || w2->chunk_len != fam.chunk_len)) return -1;
   LeafFamilyArgs<T> a;
   a.f_in = g.d_in;
   a.f_out = g.d_out;
@@ -548,8 +613,9 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.obs_off = fam.d_obs_off;
   a.c_off = fam.d_c_off;
   a.K = (int32_t)g.nodes.size();
-  a.chunks = w.chunks;
-  a.chunk_len = w.chunk_len;
+  a.chunks = fam.chunks;
+  a.chunk_len = fam.chunk_len;
+  a.chunk_base = fam.chunk_base;
   a.part_mant = w.part_mant;
   a.part_exp = w.part_exp;
   a.scaled = w.scaled;
@@ -564,7 +630,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.part_exp2 = w2 ? w2->part_exp : nullptr;
   a.scaled2 = w2 ? w2->scaled : nullptr;
   a.m_state = static_cast<T*>(fam.m_state);
-  launch(fn, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s, arena, cpts, a);
+  launch(fn, dim3(wave_blocks((int64_t)fam.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
     fam.pending = true;

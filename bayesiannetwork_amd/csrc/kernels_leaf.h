@@ -16,7 +16,8 @@ struct LeafFamilyArgs {
   const int64_t* obs_off;  // [K]    observation array of the own variable, -1 = not observed
   const int64_t* c_off;    // [K]    normaliser of the own variable
   int32_t K;
-  int32_t chunks, chunk_len;
+  int32_t chunks, chunk_len;  // this group's chunks of families
+  int32_t chunk_base;         // where they sit among the parent's chunk partials
   double* part_mant;
   int32_t* part_exp;
   const double* scaled;  // parent's P'
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       pm[s][v] = frexp(pm[s][v] * inv_pz[v], &de);
       ex[v] = (int32_t)pe[s][v] + de - pze[v];
     }
-    const int64_t row = ((int64_t)chunk * D0 + s) * a.npad + t * tile_of<T>::value + col;
+    const int64_t row = ((int64_t)(a.chunk_base + chunk) * D0 + s) * a.npad + t * tile_of<T>::value + col;
     if constexpr (V == 4) {
       *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
       *reinterpret_cast<double2*>(a.part_mant + row + 2) = make_double2(pm[s][2], pm[s][3]);
@@ -507,6 +508,62 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       a.part_exp[row] = ex[0];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Chunk partial products of a wide node from the stored messages, for either element type (the
+// float32-only wide_product_fast moves 16 bytes per lane; this one serves float64 plans, where the
+// partials are otherwise always maintained by the leaf-family kernels and only have to be rebuilt
+// when an iteration starts from message arrays that no such kernel wrote).
+//   grid.x = ceil(chunks * ntiles * parts / 4), block = 256, two observations per lane
+template <typename T, int S>
+__global__ void __launch_bounds__(256) wide_product_any(const T* __restrict__ arena, WideArgs a) {
+  constexpr int32_t V = 2, kParts = tile_of<T>::value / (64 * V);
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
+  const int32_t part = (int32_t)(w % kParts);
+  w /= kParts;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+  const int32_t col = part * 64 * V + lane * V;
+  double m[S][V];
+  int32_t e[S][V];
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      m[s][v] = 1.0;
+      e[s][v] = 0;
+    }
+  const int32_t first = a.chunk_first[chunk], last = a.chunk_first[chunk + 1];
+  for (int32_t j = first; j < last; ++j) {
+    const T* src = arena + a.in_off[a.covered[j]];
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      const fv<T, V> x = a.fresh ? splat<T, V>((T)1 / (T)S) : loadv<T, V>(src, t * S + s, col);
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) m[s][v] *= (double)x[v];
+    }
+    if (((j - first) & 3) == 3 || j + 1 == last) {
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          m[s][v] = frexp(m[s][v], &de);
+          e[s][v] += de;
+        }
+    }
+  }
+#pragma unroll
+  for (int32_t s = 0; s < S; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      const int64_t row = ((int64_t)chunk * S + s) * a.npad + t * tile_of<T>::value + col + v;
+      a.part_mant[row] = m[s][v];
+      a.part_exp[row] = e[s][v];
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -765,8 +822,8 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
     for (int32_t v = 0; v < V; ++v) dst[v] = ll_acc[v];
     return;
   }
-  store_partials<D0, V>(a.part_mant, a.part_exp, (int64_t)chunk * D0 * a.npad + t * tile_of<T>::value + col, a.npad, pm1, pe1);
-  store_partials<D1, V>(a.part_mant2, a.part_exp2, (int64_t)chunk * D1 * a.npad + t * tile_of<T>::value + col, a.npad, pm2, pe2);
+  store_partials<D0, V>(a.part_mant, a.part_exp, (int64_t)(a.chunk_base + chunk) * D0 * a.npad + t * tile_of<T>::value + col, a.npad, pm1, pe1);
+  store_partials<D1, V>(a.part_mant2, a.part_exp2, (int64_t)(a.chunk_base + chunk) * D1 * a.npad + t * tile_of<T>::value + col, a.npad, pm2, pe2);
 }
 
 // accum[entry] = cpt[entry] * sum over the per-wave sums written by the kLeafReduce kernel.

@@ -48,6 +48,7 @@ struct WideArgs {
   // partial products
   int32_t chunks, chunk_len, n_covered;
   const int32_t* covered;    // [n_covered] input slots represented in the partials, chunk order
+  const int32_t* chunk_first;  // [chunks + 1] chunk c holds covered[chunk_first[c] .. chunk_first[c + 1])
   const int32_t* uncovered;  // [n_uncovered] input slots folded by wide_combine; last = local slot
   int32_t n_uncovered;
   double* part_mant;  // [chunks][S][npad]
@@ -103,8 +104,7 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
       m[s][v] = 1.0;
       e[s][v] = 0;
     }
-  const int32_t first = chunk * a.chunk_len;
-  const int32_t last = first + a.chunk_len < a.n_covered ? first + a.chunk_len : a.n_covered;
+  const int32_t first = a.chunk_first[chunk], last = a.chunk_first[chunk + 1];
   const double u = 1.0 / (double)S;
   for (int32_t j = first; j < last; ++j) {
     if (a.fresh) {
@@ -282,8 +282,7 @@ __global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena,
     p[s][2] = hi.x;
     p[s][3] = hi.y;
   }
-  const int32_t first = chunk * a.chunk_len;
-  const int32_t last = first + a.chunk_len < a.n_covered ? first + a.chunk_len : a.n_covered;
+  const int32_t first = a.chunk_first[chunk], last = a.chunk_first[chunk + 1];
   const float uniform = 1.0f / (float)S;
   for (int32_t j = first; j < last; ++j) {
     const int32_t i = a.covered[j];

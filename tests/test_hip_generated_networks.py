@@ -112,6 +112,13 @@ def test_generated_network_matches_oracle(name, dtype, n):
     ev_dev = [evidence[o].to(ts.dtype) for o in observed_names]
     machine.enter_evidence(Evidence([e.to("cuda") for e in ev_dev], ts))
 
+    if n == 77:
+        # reading a message before anything ran makes the engine write out the initial uniform
+        # messages; the first iteration then starts from stored arrays instead of the "fresh" shortcut
+        first_leaf = by_name[spec[-1][0]]
+        initial = machine.message(first_leaf, first_leaf, "f2v")
+        assert torch.equal(initial, torch.full_like(initial, 1.0 / first_leaf.num_states))
+
     ts64, network64, by_name64 = make("cpu", "float64")
     for node, _, _ in spec:  # same rounded CPT values as the device network
         by_name64[node].cpt = by_name[node].cpt.detach().cpu().double()
