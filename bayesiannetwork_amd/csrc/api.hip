@@ -460,7 +460,7 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY(upload(p.obs_off, &p.d_obs_off, p.device_bytes));
     BN_TRY(upload(obs_states, &p.d_obs_states, p.device_bytes));
     BN_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_evidence_ptrs), p.observed.size() * sizeof(void*)));
-    p.obs_all_pairs = p.dtype == BN_F32 && p.tile % 2 == 0;
+    p.obs_all_pairs = p.tile % 2 == 0;
     for (int32_t st : obs_states) p.obs_all_pairs = p.obs_all_pairs && st == 2;
   }
   {
@@ -597,10 +597,14 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
   }
   for (size_t first = 0; first < count; first += 65535) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(count - first, 65535);
-    if (p.obs_all_pairs) {
-      bn::launch(bn::evidence_scatter_pairs, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
-                         static_cast<float*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first),
-                         p.d_obs_off + first, p.N, p.tile, p.npad);
+    if (p.obs_all_pairs && p.dtype == BN_F32) {
+      bn::launch(bn::evidence_scatter_pairs<float>, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
+                 static_cast<float*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
+                 p.N, p.tile, p.npad);
+    } else if (p.obs_all_pairs) {
+      bn::launch(bn::evidence_scatter_pairs<double>, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
+                 static_cast<double*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
+                 p.N, p.tile, p.npad);
     } else if (p.dtype == BN_F32) {
       bn::launch(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
                          (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,

@@ -273,33 +273,46 @@ __global__ void __launch_bounds__(256) store_addresses(AddressBatch batch, int32
   if (i < count) dst[i] = batch.p[i];
 }
 
-// Two-state float evidence, two observations per lane: 16 bytes in ([e0 e1 | e0 e1]), 8 bytes out
-// to each of the two state rows.  Sources that are not 16-byte aligned are read element-wise.
-// grid = (ceil(npad / 512), num_observed); tile must be even
-__global__ void __launch_bounds__(256) evidence_scatter_pairs(float* __restrict__ arena,
+// Two-state evidence, two observations per lane: one [e0 e1 | e0 e1] group in (16 bytes of float,
+// 32 of double), one pair out to each of the two state rows.  Sources that are not 16-byte aligned
+// are read element-wise.   grid = (ceil(npad / 512), num_observed); tile must be even
+template <typename T>
+__global__ void __launch_bounds__(256) evidence_scatter_pairs(T* __restrict__ arena,
                                                              const void* const* __restrict__ sources,
                                                              const int64_t* __restrict__ obs_off, int64_t N,
                                                              int32_t tile, int64_t npad) {
+  typedef T pair_t __attribute__((ext_vector_type(2)));
   const int32_t o = blockIdx.y;
   const int64_t n0 = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
   if (n0 >= npad) return;
-  const float* src = static_cast<const float*>(sources[o]);
-  float4 x = make_float4(1.f, 1.f, 1.f, 1.f);
+  const T* src = static_cast<const T*>(sources[o]);
+  T x[4] = {(T)1, (T)1, (T)1, (T)1};
   if (n0 + 1 < N) {
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      x = *reinterpret_cast<const float4*>(src + 2 * n0);
+      const pair_t a = *reinterpret_cast<const pair_t*>(src + 2 * n0);
+      const pair_t b = *reinterpret_cast<const pair_t*>(src + 2 * n0 + 2);
+      x[0] = a[0];
+      x[1] = a[1];
+      x[2] = b[0];
+      x[3] = b[1];
     } else {
-      x = make_float4(src[2 * n0], src[2 * n0 + 1], src[2 * n0 + 2], src[2 * n0 + 3]);
+#pragma unroll
+      for (int32_t i = 0; i < 4; ++i) x[i] = src[2 * n0 + i];
     }
   } else if (n0 < N) {
-    x.x = src[2 * n0];
-    x.y = src[2 * n0 + 1];
+    x[0] = src[2 * n0];
+    x[1] = src[2 * n0 + 1];
   }
   const int64_t t = n0 / tile;
   const int32_t lt = (int32_t)(n0 % tile);
-  float* dst = arena + obs_off[o] + t * 2 * tile + lt;
-  *reinterpret_cast<float2*>(dst) = make_float2(x.x, x.z);
-  *reinterpret_cast<float2*>(dst + tile) = make_float2(x.y, x.w);
+  T* dst = arena + obs_off[o] + t * 2 * tile + lt;
+  pair_t row0, row1;
+  row0[0] = x[0];
+  row0[1] = x[2];
+  row1[0] = x[1];
+  row1[1] = x[3];
+  *reinterpret_cast<pair_t*>(dst) = row0;
+  *reinterpret_cast<pair_t*>(dst + tile) = row1;
 }
 
 // Hard evidence from state indices: row s of the observation slot gets `on` where the observed

@@ -105,7 +105,7 @@ struct Plan {
   int32_t ones_states = 0;
   void* c_before = nullptr;     // snapshot of the normalisers for bn_normaliser_change (allocated on first use)
   bool c_before_valid = false;  // false: the snapshot counts as all zero
-  bool obs_all_pairs = false;  // float plan whose observed nodes all have two states
+  bool obs_all_pairs = false;  // every observed node has two states
   bool c_stale = false;        // normalisers are to read as zero (reset since the last iteration)
   int64_t* d_obs_off = nullptr;
   int32_t* d_obs_states = nullptr;
