@@ -3,15 +3,25 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 SRC   := bayesiannetwork_amd/csrc
 OUT   := bayesiannetwork_amd/libbn_hip.so
+OBJ   := build
 HDRS  := $(wildcard $(SRC)/*.h) include/bn_hip.h
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
+OBJS  := $(OBJ)/api.o $(OBJ)/exact.o $(OBJ)/plan.o
 
 all: $(OUT)
 
-$(OUT): $(SRC)/api.hip $(SRC)/plan.cpp $(HDRS)
-	$(HIPCC) $(FLAGS) -shared -o $@ $(SRC)/api.hip $(SRC)/plan.cpp
+$(OUT): $(OBJS)
+	$(HIPCC) -fPIC --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
+
+$(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(FLAGS) -c -o $@ $<
+
+$(OBJ)/%.o: $(SRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(FLAGS) -c -o $@ $<
 
 clean:
-	rm -f $(OUT)
+	rm -rf $(OUT) $(OBJ)
 
 .PHONY: all clean

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dispatch_fast.h"
+#include "error.h"
 #include "launch.h"
 #include "kernels_generic.h"
 #include "plan.h"
@@ -23,13 +24,19 @@ struct bn_plan {
 };
 
 namespace {
-
 thread_local std::string g_error = "";
+}
 
+namespace bn {
 int fail(int code, const std::string& msg) {
   g_error = msg;
   return code;
 }
+}  // namespace bn
+
+namespace {
+
+using bn::fail;
 
 #define BN_HIP_CHECK(expr)                                                                   \
   do {                                                                                       \

@@ -73,6 +73,18 @@ def _declare(lib):
     lib.bn_normaliser_change.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.bn_get_message.restype = c_int
     lib.bn_get_message.argtypes = [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.bn_exact_create.restype = c_int
+    lib.bn_exact_create.argtypes = [c_int, c_int32, i32p, i32p, i32p, i32p, c_int32, POINTER(c_void_p)]
+    lib.bn_exact_destroy.restype = c_int
+    lib.bn_exact_destroy.argtypes = [c_void_p]
+    lib.bn_exact_set_cpts.restype = c_int
+    lib.bn_exact_set_cpts.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.bn_exact_enter_evidence.restype = c_int
+    lib.bn_exact_enter_evidence.argtypes = [c_void_p, c_int64, POINTER(c_void_p), c_void_p]
+    lib.bn_exact_log_likelihood.restype = c_int
+    lib.bn_exact_log_likelihood.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.bn_exact_marginal.restype = c_int
+    lib.bn_exact_marginal.argtypes = [c_void_p, i32p, c_int32, c_void_p, c_void_p]
     lib.bn_profile_enable.restype = c_int
     lib.bn_profile_enable.argtypes = [c_int32]
     lib.bn_profile_only.restype = c_int
@@ -86,6 +98,8 @@ EXPORTS = (
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_m_step", "bn_normaliser_change", "bn_get_message",
+    "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
+    "bn_exact_log_likelihood", "bn_exact_marginal",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only",
 )
 

@@ -218,6 +218,57 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
                    void* stream);
 
 /*
+ * Exact inference by enumeration of the joint distribution, for checking sum-product results on
+ * small networks (trees, polytrees, loopy networks).  Replaces the reference's brute-force machine
+ * (inference_machines/naive/naive_inference_machine.py:11-122): that one materialises
+ * p(all nodes) * evidence as an [N, d_1..d_n] tensor; this one sums the nodes that are neither
+ * queried nor observed once per query, then walks the observed nodes' joint states per observation.
+ * Sums are carried in double for both dtypes.  Limits: 32 nodes, 2^30 joint states, 2^24 joint
+ * states over (query + observed) nodes of one query.
+ *
+ * Unlike the reference, which reshapes each CPT assuming its parents precede it in ascending node
+ * order (naive_inference_machine.py:45-55), CPT axes are matched to parents by parent_indices, so
+ * any node order gives the right joint.
+ */
+typedef struct bn_exact bn_exact;
+
+/* Topology arguments as bn_plan_create.  Bound to the current HIP device. */
+int bn_exact_create(int dtype, int32_t num_nodes, const int32_t* num_states, const int32_t* parent_offsets,
+                    const int32_t* parent_indices, const int32_t* observed_nodes, int32_t num_observed,
+                    bn_exact** out_machine);
+int bn_exact_destroy(bn_exact* machine);
+
+/* Snapshot the flat CPT buffer (device pointer, machine dtype); the reference builds its joint
+ * table at construction (naive_inference_machine.py:30, :37-57). */
+int bn_exact_set_cpts(bn_exact* machine, const void* cpts_dev, void* stream);
+
+/*
+ * Copy the evidence (addresses as bn_enter_evidence; num_observations may change from call to
+ * call) and compute the probability of the evidence c[n] of every observation
+ * (naive_inference_machine.py:59-88).  evidence_dev == NULL enters all-ones evidence, the
+ * reference's state before enter_evidence (:31): queries then return prior marginals.
+ */
+int bn_exact_enter_evidence(bn_exact* machine, int64_t num_observations, const void* const* evidence_dev,
+                            void* stream);
+
+/*
+ * log c[n]: their sum (mean when average != 0) as one double to total_out_dev, and/or each of
+ * them, in the machine dtype, to each_out_dev[num_observations]; either may be NULL
+ * (naive_inference_machine.py:88, :112-122).
+ */
+int bn_exact_log_likelihood(bn_exact* machine, int32_t average, double* total_out_dev, void* each_out_dev,
+                            void* stream);
+
+/*
+ * Posterior over a set of distinct nodes given the evidence:
+ * out_dev[N, states(nodes[0]), .., states(nodes[k-1])], machine dtype, normalised by c[n]
+ * (naive_inference_machine.py:90-110; the reference returns the axes in ascending node order,
+ * which a caller gets by passing the nodes sorted).
+ */
+int bn_exact_marginal(bn_exact* machine, const int32_t* nodes, int32_t num_query_nodes, void* out_dev,
+                      void* stream);
+
+/*
  * Per-kernel timing for benchmarks (process-wide switch): while enabled, every kernel any
  * plan launches carries a start/stop hipEvent pair attached to its dispatch (no marker
  * packets are put between kernels).

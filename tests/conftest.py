@@ -57,9 +57,13 @@ class Fixture:
         return [torch.from_numpy(self.z["ev/" + o]).to(device) for o in self.meta["observed"]]
 
 
-def fixture_names(prefix_exclude=("em_",)):
+def fixture_names(prefix_exclude=("em_", "naive_")):
     names = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
     return [n for n in names if not n.startswith(prefix_exclude)]
+
+
+def naive_fixture_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("naive_"))
 
 
 def em_fixture_names():
