@@ -324,6 +324,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
       }
       prof_end(s);
     }
+    bn::set_ingest_next(p, false);  // the observation arrays now hold the evidence
   }
   return BN_OK;
 }
@@ -376,6 +377,50 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
     if (bn::finalize_em_fast(p, (size_t)(g - p.fgroups.data()), accum, s) <= 0)
       return fail(BN_ERR_HIP, "launch of em_finalize_slots failed");
     prof_end(s);
+  }
+  return BN_OK;
+}
+
+// The table of evidence source addresses, on the device (kernel arguments carry it over, a batch
+// per launch); skipped when the sources are the same as last time.
+int upload_evidence_table(bn::Plan& p, const void* const* evidence_dev, hipStream_t s) {
+  const size_t count = p.observed.size();
+  const bool same_table = p.evidence_on_device.size() == count &&
+                          std::memcmp(p.evidence_on_device.data(), evidence_dev, count * sizeof(void*)) == 0;
+  if (same_table) return BN_OK;
+  for (size_t first = 0; first < count; first += bn::kAddressBatch) {
+    const int32_t cnt = (int32_t)std::min<size_t>(count - first, bn::kAddressBatch);
+    bn::AddressBatch batch;
+    std::memcpy(batch.p, evidence_dev + first, (size_t)cnt * sizeof(void*));
+    bn::launch(bn::store_addresses, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, batch, cnt,
+               const_cast<const void**>(p.d_evidence_ptrs) + first);
+    BN_LAUNCH_CHECK("store_addresses");
+  }
+  p.evidence_on_device.assign(evidence_dev, evidence_dev + count);
+  return BN_OK;
+}
+
+// For an ingesting first iteration: per fused family group, the evidence source of every leaf in
+// the group's own order (the leaf's all-ones stand-in array when it is not observed).
+int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStream_t s) {
+  bn::FastState* st = bn::fast_state(p);
+  for (auto& kv : st->fused) {
+    bn::FusedFamily& fam = kv.second;
+    const bn::FactorGroup& g = p.fgroups[kv.first];
+    if (fam.wide_index2 >= 0 || g.dims[1] != 2) continue;
+    const char* ones = static_cast<const char*>(p.arena) + (size_t)p.ones_off * p.elem_size;
+    std::vector<const void*> src(g.nodes.size());
+    for (size_t k = 0; k < src.size(); ++k) src[k] = fam.ev_index[k] >= 0 ? evidence_dev[fam.ev_index[k]] : ones;
+    if (src == fam.src_on_device) continue;
+    for (size_t first = 0; first < src.size(); first += bn::kAddressBatch) {
+      const int32_t cnt = (int32_t)std::min<size_t>(src.size() - first, bn::kAddressBatch);
+      bn::AddressBatch batch;
+      std::memcpy(batch.p, src.data() + first, (size_t)cnt * sizeof(void*));
+      bn::launch(bn::store_addresses, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, batch, cnt,
+                 fam.d_src + first);
+      BN_LAUNCH_CHECK("store_addresses");
+    }
+    fam.src_on_device.swap(src);
   }
   return BN_OK;
 }
@@ -582,20 +627,7 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
     if (!evidence_dev[i]) return fail(BN_ERR_INVALID, "an evidence pointer is null");
     max_states = std::max(max_states, p.states[p.observed[i]]);
   }
-  // same sources as last time: the device table is already right
-  const bool same_table = p.evidence_on_device.size() == count &&
-                          std::memcmp(p.evidence_on_device.data(), evidence_dev, count * sizeof(void*)) == 0;
-  if (!same_table) {
-    for (size_t first = 0; first < count; first += bn::kAddressBatch) {
-      const int32_t cnt = (int32_t)std::min<size_t>(count - first, bn::kAddressBatch);
-      bn::AddressBatch batch;
-      std::memcpy(batch.p, evidence_dev + first, (size_t)cnt * sizeof(void*));
-      bn::launch(bn::store_addresses, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, batch, cnt,
-                 const_cast<const void**>(p.d_evidence_ptrs) + first);
-      BN_LAUNCH_CHECK("store_addresses");
-    }
-    p.evidence_on_device.assign(evidence_dev, evidence_dev + count);
-  }
+  if (int rc = upload_evidence_table(p, evidence_dev, s)) return rc;
   const uint32_t gx = (uint32_t)(((int64_t)max_states * p.npad + 255) / 256);
   {
     double bytes = 0;
@@ -842,6 +874,34 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   }
   if (rc != BN_OK || !accum_dev) return rc;
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
+}
+
+int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_t num_iterations, int32_t average,
+                          double* ll_out_dev, double* accum_dev, void* stream) {
+  if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
+  bn::Plan& p = plan->p;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // The first iteration can take the evidence straight from the caller's arrays when nothing has
+  // been sent yet, it is not also the last one (that one may have to be re-run later, after the
+  // caller's arrays are gone), and the arrays allow whole-lane loads.
+  bool ingest = !p.observed.empty() && evidence_dev && p.fresh && num_iterations >= 2 && p.N >= 2 &&
+                bn::ingest_possible(p);
+  if (ingest)
+    for (size_t i = 0; i < p.observed.size() && ingest; ++i)
+      ingest = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
+  if (!ingest) {
+    if (int rc = bn_enter_evidence(plan, evidence_dev, stream)) return rc;
+    return bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
+  }
+  if (int rc = complete_pending(p, s)) return rc;
+  if (int rc = upload_family_sources(p, evidence_dev, s)) return rc;
+  p.obs_pending = false;  // the first factor pass writes every observation array
+  bn::set_ingest_next(p, true);
+  const int rc = bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
+  bn::set_ingest_next(p, false);
+  return rc;
 }
 
 int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,

@@ -52,6 +52,9 @@ struct FusedFamily {
   void* m_state = nullptr;      // [K][D0 + D1][npad] of the plan's element type: two-parent loop state (previous messages to the parents)
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
+  std::vector<int32_t> ev_index;   // [K] position of each leaf in the evidence order, -1 = not observed
+  const void** d_src = nullptr;    // [K] evidence source of each leaf for an ingesting launch
+  std::vector<const void*> src_on_device;  // what d_src holds
   void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
   void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
   int32_t slots = 0;
@@ -77,6 +80,10 @@ struct FastState {
   // parentless factor groups whose output (the prior, broadcast over observations) is already in
   // place: it only changes with the CPTs
   std::vector<char> root_written;
+  // Every observed node is a two-state leaf of a one-parent fused family: the first iteration
+  // after a reset can read the evidence from the caller's arrays and write the arena copy itself.
+  bool ingest_ok = false;
+  bool ingest_next = false;  // the coming first iteration does so (evidence pointers are on the device)
 };
 
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
@@ -120,6 +127,7 @@ inline void release_fast(Plan& p) {
   for (auto& kv : st->fused) {
     if (kv.second.d_obs_off) (void)hipFree(kv.second.d_obs_off);
     if (kv.second.d_c_off) (void)hipFree(kv.second.d_c_off);
+    if (kv.second.d_src) (void)hipFree(kv.second.d_src);
     if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
     if (kv.second.z_state) (void)hipFree(kv.second.z_state);
     if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
@@ -139,6 +147,15 @@ inline void invalidate_fast(Plan& p) {
     }
     std::fill(st->root_written.begin(), st->root_written.end(), 0);
   }
+}
+
+inline bool ingest_possible(const Plan& p) {
+  FastState* st = fast_state(p);
+  return st && st->ingest_ok;
+}
+
+inline void set_ingest_next(Plan& p, bool on) {
+  if (FastState* st = fast_state(p)) st->ingest_next = on;
 }
 
 inline void cpts_changed_fast(Plan& p) {
@@ -239,10 +256,13 @@ inline int prepare_fast(Plan& p) {
     std::vector<int64_t> obs, cs;
     for (int32_t j : g.nodes) {
       obs.push_back(p.observed_slot_of[j] >= 0 ? p.obs_off[p.observed_slot_of[j]] : p.ones_off);
+      fam.ev_index.push_back(p.observed_slot_of[j]);
       cs.push_back(p.c_off[j]);
       handled[j] = 1;
     }
     if (!dev_upload(obs, &fam.d_obs_off, p.device_bytes) || !dev_upload(cs, &fam.d_c_off, p.device_bytes)) return -2;
+    if (hipMalloc(reinterpret_cast<void**>(&fam.d_src), g.nodes.size() * sizeof(void*)) != hipSuccess) return -2;
+    p.device_bytes += (int64_t)(g.nodes.size() * sizeof(void*));
     fam.slots = (int32_t)(p.ntiles * leaf_parts(p));
     const size_t em_elems = g.nodes.size() * (size_t)g.cpt_elems * fam.slots;
     if (hipMalloc(reinterpret_cast<void**>(&fam.em_partial), em_elems * (size_t)p.elem_size) != hipSuccess) return -2;
@@ -264,7 +284,7 @@ inline int prepare_fast(Plan& p) {
     auto it = st.fused.find(fi);
     if (it == st.fused.end()) return;
     FusedFamily& fam = it->second;
-    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, fam.em_partial, fam.z_state, fam.m_state})
+    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, (void*)fam.d_src, fam.em_partial, fam.z_state, fam.m_state})
       if (buffer) (void)hipFree(buffer);
     for (int32_t j : p.fgroups[fi].nodes) handled[j] = 0;
     for (int32_t widx : {fam.wide_index, fam.wide_index2}) {
@@ -297,6 +317,14 @@ inline int prepare_fast(Plan& p) {
     bool all = true;
     for (int32_t j : p.vgroups[gi].nodes) all = all && handled[j];
     st.vgroup_skip[gi] = all ? 1 : 0;
+  }
+  {
+    std::vector<char> ingestible(p.n_nodes, 0);
+    for (const auto& kv : st.fused)
+      if (kv.second.wide_index2 < 0 && p.fgroups[kv.first].dims[1] == 2)
+        for (int32_t j : p.fgroups[kv.first].nodes) ingestible[j] = 1;
+    st.ingest_ok = kLeafVec == 2 && !p.observed.empty();
+    for (int32_t o : p.observed) st.ingest_ok = st.ingest_ok && ingestible[o];
   }
   {
     std::vector<int64_t> offs;
@@ -577,6 +605,19 @@ inline LeafFamilyFn<T> leaf_family_for_s(int32_t s) {
   return nullptr;
 }
 
+// two-state leaves only (the ingesting launch)
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_lookup_pairs(int32_t d0) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_family_p1<T, DV, 2, kLeafVec, MODE>;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
 template <typename T, int MODE>
 inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
@@ -594,9 +635,13 @@ template <typename T>
 inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena,
                               const T* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
                               bool with_counts = true) {
-  const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+  int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+  if (fresh && mode == kLeafLoop && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next) state = kLeafIngest;
   LeafFamilyFn<T> fn = nullptr;
   switch (mode + 3 * state) {
+    case kLeafLoop + 3 * kLeafIngest:
+      fn = leaf_family_lookup_pairs<T, kLeafLoop + 3 * kLeafIngest>(g.dims[0]);
+      break;
 #define X(M)                                                                                                    \
   case M:                                                                                                       \
     fn = w2 ? leaf_family_p2<T, 2, 2, 2, kLeafVec, M> : leaf_family_lookup<T, M>(g.dims[0], g.dims[1]);         \
@@ -630,6 +675,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.part_exp2 = w2 ? w2->part_exp : nullptr;
   a.scaled2 = w2 ? w2->scaled : nullptr;
   a.m_state = static_cast<T*>(fam.m_state);
+  a.src = fam.d_src;
   launch(fn, dim3(wave_blocks((int64_t)fam.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {

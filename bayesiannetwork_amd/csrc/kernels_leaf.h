@@ -35,6 +35,9 @@ struct LeafFamilyArgs {
   int32_t* part_exp2;
   const double* scaled2;
   T* m_state;  // [K][D0 + D1][npad]
+  // kLeafIngest only: per family, the caller's evidence array ([N][2], row-major) of its leaf, or
+  // the leaf's stand-in observation array in the arena (all ones) when it is not observed
+  const void* const* src;
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
@@ -50,7 +53,10 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 //   kLeafSteady      the loop state a kLeafLoop launch left (z_state);
 //   kLeafFresh       nothing has been sent yet: every message still has its initial uniform value;
 //   kLeafFromArrays  the message arrays a kLeafFull launch wrote.
-constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2;
+//   kLeafIngest      as kLeafFresh, and the observations have not been copied into the arena yet:
+//                    they are read from the caller's arrays and the arena copy is written on the
+//                    way (two-state leaves, two observations per lane, kLeafLoop only).
+constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafIngest = 3;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -149,6 +155,7 @@ struct LeafPtrs {  // wave-uniform
   T* z;          // loop-state normaliser of this family
   const T* obs;  // the observation, or an all-ones array when the leaf is not observed
   const T* cpt;
+  const T* src;  // ingesting launches: the caller's evidence array of this leaf (== obs when not observed)
 };
 
 template <typename T, int S, int V>
@@ -157,7 +164,7 @@ struct LeafState {
   fv<T, V> z;  // the leaf's normaliser for this iteration: sum_s ev[s] * (previous message from the factor)[s]
 };
 
-template <typename T>
+template <typename T, bool INGEST = false>
 __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T* __restrict__ cpts,
                                                  const LeafFamilyArgs<T>& a, int32_t k) {
   LeafPtrs<T> p;
@@ -169,6 +176,8 @@ __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T*
   p.z = a.z_state + (int64_t)k * a.npad;
   p.obs = arena + a.obs_off[k];
   p.cpt = cpts + a.cpt_off[k];
+  p.src = nullptr;
+  if constexpr (INGEST) p.src = static_cast<const T*>(a.src[k]);
   return p;
 }
 
@@ -188,12 +197,32 @@ __device__ __forceinline__ fv<T, V> recipv(const fv<T, V>& x) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, splat<T, V>(1.f)), r, r);
 }
 
-template <typename T, int S, int V, int STATE>
+template <typename T, int S, int V, int STATE, bool INGEST = false>
 __device__ __forceinline__ LeafState<T, S, V> leaf_state(const LeafPtrs<T>& p, const LeafFamilyArgs<T>& a, int64_t t,
                                                       int32_t col) {
   LeafState<T, S, V> st;
+  if constexpr (INGEST && S == 2 && V == 2) {
+    // This lane's two observations are four consecutive elements of the caller's [N][2] array
+    // (an unobserved leaf reads the all-ones array instead).  Branch-free: a lane whose second
+    // observation lies beyond N loads the array's last four elements and takes the last pair as
+    // its first observation; what padding observations hold does not matter.
+    const int64_t n0 = t * tile_of<T>::value + col;
+    const bool tail = n0 + 1 >= a.N;
+    const int64_t at = tail ? a.N - 2 : n0;
+    const fv<T, 4> raw = *reinterpret_cast<const fv<T, 4>*>(p.src + at * 2);
+    st.ev[0][0] = tail ? raw[2] : raw[0];
+    st.ev[1][0] = tail ? raw[3] : raw[1];
+    st.ev[0][1] = raw[2];
+    st.ev[1][1] = raw[3];
+    // The arena copy.  Unconditional (a branch here costs the loop its register budget): an
+    // unobserved leaf writes the ones it has just read back into the shared all-ones array.
+    T* dst = const_cast<T*>(p.obs);
+    storev<T, V>(dst, t * S, col, st.ev[0]);
+    storev<T, V>(dst, t * S + 1, col, st.ev[1]);
+  } else {
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
+    for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
+  }
   if constexpr (STATE != kLeafSteady) {
     fv<T, V> own[S];
 #pragma unroll
@@ -218,7 +247,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
                                                      LeafFamilyArgs<T> a) {
   constexpr bool FULL = MODE % 3 == kLeafFull;
   constexpr bool REDUCE = MODE % 3 == kLeafReduce;
-  constexpr int32_t STATE = MODE / 3;
+  constexpr bool INGEST = MODE / 3 == kLeafIngest;
+  constexpr int32_t STATE = INGEST ? kLeafFresh : MODE / 3;
   constexpr int32_t kParts = tile_of<T>::value / (64 * V);
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -283,12 +313,12 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     pze[v] = 0;
   }
 
-  LeafPtrs<T> ptr = leaf_ptrs(arena, cpts, a, first);
-  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE>(ptr, a, t, col);
+  LeafPtrs<T> ptr = leaf_ptrs<T, INGEST>(arena, cpts, a, first);
+  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE, INGEST>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
     const int32_t kn = k + 1 < last ? k + 1 : k;
-    const LeafPtrs<T> ptr_next = leaf_ptrs(arena, cpts, a, kn);
-    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE>(ptr_next, a, t, col);
+    const LeafPtrs<T> ptr_next = leaf_ptrs<T, INGEST>(arena, cpts, a, kn);
+    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE, INGEST>(ptr_next, a, t, col);
     const T* cpt = ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the

@@ -262,6 +262,15 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def enter_evidence(self, evidence: Evidence) -> None:
         if isinstance(evidence, HardEvidence):
             return self._enter_hard_evidence(evidence)
+        cached = self._evidence_table(evidence)
+        with torch.cuda.device(self._device):
+            _native.check(self._lib.bn_enter_evidence(self._plan, cached[2], self._stream()))
+        self._evidence_keepalive = cached
+        self.must_iterate = True
+
+    def _evidence_table(self, evidence: Evidence):
+        """``(key, tensors, table of their device addresses)`` for the engine, cached on the
+        evidence object; tensors are checked against the observed nodes."""
         key = (self._device, self._dtype, self._n)
         cached = getattr(evidence, "_hip_table", None)
         if cached is None or cached[0] != key:
@@ -284,10 +293,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
                 evidence._hip_table = cached
             except AttributeError:
                 pass
-        with torch.cuda.device(self._device):
-            _native.check(self._lib.bn_enter_evidence(self._plan, cached[2], self._stream()))
-        self._evidence_keepalive = cached
-        self.must_iterate = True
+        return cached
 
     def _enter_hard_evidence(self, evidence: HardEvidence) -> None:
         """State indices go to the engine as they are (one byte per observed node and observation);
@@ -409,22 +415,39 @@ class HipSpaInferenceMachine(IInferenceMachine):
             _native.check(self._lib.bn_em_accumulate(self._plan, ctypes.c_void_p(out.data_ptr()), self._stream()))
         return out
 
-    def em_statistics(self):
+    def em_statistics(self, evidence: Optional[Evidence] = None):
         """``(log_likelihood_tensor, expected_count_sums)`` of the entered evidence in one engine call.
         When the iterations have not run yet (and no per-iteration callback is set) the last
         iteration is evaluated on the fly for the statistics; message queries made afterwards
-        bring the stored messages up to date first, so results are the same either way."""
-        if not self.must_iterate or self._settings.callback or self._settings.convergence_tolerance is not None:
+        bring the stored messages up to date first, so results are the same either way.
+
+        With ``evidence`` the call is ``enter_evidence(evidence)`` followed by ``em_statistics()``;
+        the engine then gets both in one call and may read the evidence while it runs the first
+        iteration instead of copying it first (same results, same state afterwards)."""
+        plain = self._settings.callback is None and self._settings.convergence_tolerance is None
+        if evidence is not None and (isinstance(evidence, HardEvidence) or not plain):
+            self.enter_evidence(evidence)
+            evidence = None
+        if evidence is None and (not self.must_iterate or not plain):
             return self.log_likelihood_tensor(), self.expected_count_sums()
         ll = torch.empty((1,), device=self._device, dtype=torch.float64)
         counts = torch.empty((self._lib.bn_plan_cpt_elements(self._plan),), device=self._device, dtype=torch.float64)
+        average = 1 if self._settings.average_log_likelihood else 0
         with torch.cuda.device(self._device):
-            _native.check(
-                self._lib.bn_em_statistics(self._plan, self._num_iterations,
-                                           1 if self._settings.average_log_likelihood else 0,
-                                           ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
-                                           self._stream())
-            )
+            if evidence is not None:
+                cached = self._evidence_table(evidence)
+                _native.check(
+                    self._lib.bn_em_statistics_from(self._plan, cached[2], self._num_iterations, average,
+                                                    ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                                    self._stream())
+                )
+                self._evidence_keepalive = cached
+            else:
+                _native.check(
+                    self._lib.bn_em_statistics(self._plan, self._num_iterations, average,
+                                               ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                               self._stream())
+                )
         self.must_iterate = False
         self.iterations_run = self._num_iterations
         return ll, counts

@@ -42,14 +42,15 @@ class EmBatchOptimizer(IBatchOptimizer):
             pending = []
             for iteration, evidence in enumerate(evidence_loader):
                 machine = self._factory(self._network)
-                machine.enter_evidence(evidence)
                 deferred = cfg.deferred_logging and hasattr(machine, "log_likelihood_tensor")
                 count_sums = None
                 if hasattr(machine, "em_statistics"):
-                    ll, count_sums = machine.em_statistics()
+                    # evidence, iterations, log-likelihood and expected counts in one engine call
+                    ll, count_sums = machine.em_statistics(evidence)
                     if not deferred:
                         ll = ll.item()
                 else:
+                    machine.enter_evidence(evidence)
                     ll = machine.log_likelihood_tensor() if deferred else machine.log_likelihood()
                 if hasattr(machine, "expected_count_sums"):
                     # whole-network M-step on one flat buffer; nodes get views of it

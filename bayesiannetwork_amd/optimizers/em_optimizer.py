@@ -32,12 +32,12 @@ class EmOptimizer(IOptimizer):
         flat_model = None
         for iteration in range(self._settings.num_iterations):
             machine = self._factory(self._network)
-            machine.enter_evidence(evidence)
             count_sums = None
             if hasattr(machine, "em_statistics"):
-                ll, count_sums = machine.em_statistics()
+                ll, count_sums = machine.em_statistics(evidence)
                 ll = ll.item()
             else:
+                machine.enter_evidence(evidence)
                 ll = machine.log_likelihood()
             if hasattr(machine, "expected_count_sums"):
                 if flat_model is None:

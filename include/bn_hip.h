@@ -179,6 +179,20 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
                      void* stream);
 
 /*
+ * bn_enter_evidence followed by bn_em_statistics, as one call: same arguments, same results, same
+ * state afterwards (the observation slots hold the evidence).  When nothing has been sent since
+ * the last reset, at least two iterations are asked for, every observed node is a two-state leaf
+ * served by a fused leaf-family kernel and the evidence arrays are 32-byte aligned, the first
+ * iteration reads the evidence from the caller's arrays and writes the plan's copy on the way,
+ * which saves the separate copy pass; otherwise it is literally the two calls.  The evidence
+ * arrays are not referenced after the call's work on the stream has finished.
+ * Replaces enter_evidence + log_likelihood + _e_step of one optimizer step
+ * (optimizers/em_batch_optimizer.py:44-48, optimizers/em_optimizer.py:34-41).
+ */
+int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_t num_iterations, int32_t average,
+                          double* ll_out_dev, double* accum_dev, void* stream);
+
+/*
  * M-step for the whole network in one launch.  For every CPT row (last axis) of every node:
  *   target = count_sums_row / sum(count_sums_row)
  *   target = (1 - regularization) * target + regularization / num_states      if regularization != 0

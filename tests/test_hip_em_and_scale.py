@@ -180,6 +180,79 @@ def test_em_statistics_equals_separate_calls_and_leaves_queries_intact(name):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n,offset", [(24, 0), (77, 0), (300, 0), (1025, 0), (300, 1)])
+def test_em_statistics_with_evidence_equals_enter_evidence_then_statistics(dtype, n, offset):
+    """bn_em_statistics_from = bn_enter_evidence + bn_em_statistics: on the 784-leaf model the first
+    iteration reads the caller's evidence arrays itself.  Log-likelihood and counts must be bit-identical
+    to the two-call route (same arithmetic on the same values), the observation slots must hold the
+    evidence bit for bit afterwards, and later queries must agree.  Odd N and N not a multiple of the
+    tile exercise the partly filled lanes; offset 1 makes the arrays 8-byte aligned only, which must
+    take the two-call route inside the engine (same results)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture("c3a_784_f64" if dtype == "float64" else "c3a_784_f32")
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    network, observed, by_name = fx.build(ts)
+    gen = torch.Generator().manual_seed(n)
+    rows = []
+    for node in observed:
+        soft = torch.rand((n + offset, 2), generator=gen, dtype=torch.float64) + 1e-3
+        rows.append(soft.to(ts.dtype).to("cuda")[offset:])
+    assert all(r.is_contiguous() for r in rows)
+    ev = Evidence(rows, ts)
+    assert (ev.data[0].data_ptr() % 32 == 0) == (offset == 0)
+    settings = SpaInferenceMachineSettings(ts, False)
+
+    two_calls = HipSpaInferenceMachine(settings, network, observed, n)
+    two_calls.enter_evidence(ev)
+    ll_a, counts_a = two_calls.em_statistics()
+    one_call = HipSpaInferenceMachine(settings, network, observed, n)
+    ll_b, counts_b = one_call.em_statistics(ev)
+    assert ll_a.item() == ll_b.item()
+    assert torch.equal(counts_a, counts_b)
+    assert not one_call.must_iterate
+    for node, src in list(zip(observed, ev.data))[::97]:
+        assert torch.equal(one_call.observation(node), src), node.name
+    probe = [by_name["Q"], observed[0], observed[391], observed[-1]]
+    for a, b in zip(one_call.infer_single_nodes(probe), two_calls.infer_single_nodes(probe)):
+        assert torch.equal(a, b)
+    for a, b in zip(one_call.infer_nodes_with_parents(probe), two_calls.infer_nodes_with_parents(probe)):
+        assert torch.equal(a, b)
+    # a second batch on the same machines: messages are no longer fresh, both take the copying route
+    ev2 = Evidence([torch.flip(r, dims=[0]).contiguous() for r in rows], ts)
+    two_calls.enter_evidence(ev2)
+    ll_a, counts_a = two_calls.em_statistics()
+    ll_b, counts_b = one_call.em_statistics(ev2)
+    assert ll_a.item() == ll_b.item() and torch.equal(counts_a, counts_b)
+
+
+def test_em_statistics_with_evidence_on_networks_without_the_fused_path():
+    """Networks whose observed nodes are not all two-state leaves of a fused family (docs network,
+    loopy 784-leaf model) and a one-iteration run take the two-call route; results unchanged."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype="float32")
+    for name, iterations in (("c2_docs2_f32", None), ("c3b_784_f32", 10), ("c3a_784_f32", 1)):
+        fx = Fixture(name)
+        network, observed, by_name = fx.build(ts)
+        settings = SpaInferenceMachineSettings(ts, True, num_iterations=iterations, allow_loops=fx.meta["allow_loops"])
+        ev = Evidence(fx.evidence_tensors("cuda"), ts)
+        a = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
+        a.enter_evidence(ev)
+        ll_a, counts_a = a.em_statistics()
+        b = HipSpaInferenceMachine(settings, network, observed, fx.meta["N"])
+        ll_b, counts_b = b.em_statistics(ev)
+        assert ll_a.item() == ll_b.item() and torch.equal(counts_a, counts_b), name
+        nodes = list(network.nodes)[:5]
+        for x, y in zip(a.infer_single_nodes(nodes), b.infer_single_nodes(nodes)):
+            assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("lr,reg", [(None, None), (0.1, 0.01), (0.3, None), (None, 0.05)])
 def test_m_step_kernel_equals_the_tensor_formulas(dtype, lr, reg):
     """bn_m_step against the same M-step written with torch tensor operations (FlatModel.m_step,
