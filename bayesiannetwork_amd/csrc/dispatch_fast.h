@@ -818,9 +818,10 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       launch(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;
     }
-    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      launch((factor_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt,
-                         K, p.ntiles);
+    if (g.dims.size() == 3) {
+      FactorP1Fn fn = factor_p2_lookup(g.dims[0], g.dims[1], g.dims[2]);
+      if (!fn) return 0;
+      launch(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;
     }
     return 0;
@@ -855,9 +856,10 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, d
       launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
       return launch_ok() ? 1 : -1;
     }
-    if (g.dims.size() == 3 && g.dims[0] == 2 && g.dims[1] == 2 && g.dims[2] == 2) {
-      launch((em_p2_fast<2, 2, 2>), dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles,
-                         nchunks, partial);
+    if (g.dims.size() == 3) {
+      EmP1Fn fn = em_p2_lookup(g.dims[0], g.dims[1], g.dims[2]);
+      if (!fn) return 0;
+      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
       return launch_ok() ? 1 : -1;
     }
     return 0;

@@ -469,6 +469,83 @@ inline EmP1Fn em_p1_lookup(int32_t d0, int32_t s) {
   return nullptr;
 }
 
+// Two-parent families: every shape with cardinalities 2..5 whose CPT has at most 40 entries (the
+// EM kernel keeps one double accumulator per entry in registers).
+#define BN_P2_DIMS(X) X(2) X(3) X(4) X(5)
+constexpr int32_t kP2MaxEntries = 40;
+
+template <int D0, int D1>
+inline FactorP1Fn factor_p2_for_s(int32_t s) {
+  switch (s) {
+#define X(SV)                                                          \
+  case SV:                                                             \
+    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return factor_p2_fast<D0, D1, SV>; \
+    break;
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+template <int D0>
+inline FactorP1Fn factor_p2_for_d1(int32_t d1, int32_t s) {
+  switch (d1) {
+#define X(DV) \
+  case DV:    \
+    return factor_p2_for_s<D0, DV>(s);
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+inline FactorP1Fn factor_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return factor_p2_for_d1<DV>(d1, s);
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+template <int D0, int D1>
+inline EmP1Fn em_p2_for_s(int32_t s) {
+  switch (s) {
+#define X(SV)                                                      \
+  case SV:                                                         \
+    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return em_p2_fast<D0, D1, SV>; \
+    break;
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+template <int D0>
+inline EmP1Fn em_p2_for_d1(int32_t d1, int32_t s) {
+  switch (d1) {
+#define X(DV) \
+  case DV:    \
+    return em_p2_for_s<D0, DV>(s);
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+inline EmP1Fn em_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return em_p2_for_d1<DV>(d1, s);
+    BN_P2_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
 inline EmP1Fn em_root_lookup(int32_t s) {
   switch (s) {
 #define X(SV) \
