@@ -59,7 +59,9 @@ struct FusedFamily {
   void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
   int32_t slots = 0;
   double* ll_part = nullptr;    // [chunks][npad], written by the reduce-mode kernel
-  int32_t ll_rows = 0;
+  int32_t ll_rows = 0;          // rows the last reduce-mode launch wrote
+  int32_t ll_rows_cap = 0;      // rows allocated
+  int32_t slots_used = 0;       // per-wave sum slots the last reduce-mode launch wrote
   // the last iteration ran in reduce mode: stored messages are one iteration behind until
   // complete_pending_fast re-runs it in full mode with these flags
   bool pending = false;
@@ -391,9 +393,10 @@ inline int prepare_fast(Plan& p) {
       FusedFamily& fam = st.fused[fi];
       if (fam.ll_part) continue;  // a two-parent group is visited from both its parents
       fam.ll_rows = fam.chunks;
-      if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.chunks * p.npad * sizeof(double)) != hipSuccess)
+      fam.ll_rows_cap = std::max(fam.chunks, 32);
+      if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.ll_rows_cap * p.npad * sizeof(double)) != hipSuccess)
         return -2;
-      p.device_bytes += (int64_t)((size_t)fam.chunks * p.npad * sizeof(double));
+      p.device_bytes += (int64_t)((size_t)fam.ll_rows_cap * p.npad * sizeof(double));
     }
   }
   return 0;
@@ -618,6 +621,19 @@ inline LeafFamilyFn<T> leaf_family_lookup_pairs(int32_t d0) {
   return nullptr;
 }
 
+// reduce-mode launches of two-state leaves with four observations per lane
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_lookup_pairs4(int32_t d0) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_family_p1<T, DV, 2, 4, MODE>;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
 template <typename T, int MODE>
 inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
   switch (d0) {
@@ -649,6 +665,29 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
   }
+  // Reduce mode writes no partial products, so it is free to cut the families differently: with
+  // four observations per lane (one wave per tile and chunk) the count sums cross the lanes half
+  // as often per observation.
+  bool wide4 = false;
+  int32_t chunks_r = 0;
+  if constexpr (std::is_same<T, float>::value) {
+    if (mode == kLeafReduce && !w2 && g.dims[1] == 2 && p.tile == 256 && !getenv("BN_REDUCE_V2")) {
+      LeafFamilyFn<T> fn4 = nullptr;
+      switch (state) {
+        case kLeafSteady: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafSteady>(g.dims[0]); break;
+        case kLeafFresh: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFresh>(g.dims[0]); break;
+        case kLeafFromArrays: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFromArrays>(g.dims[0]); break;
+      }
+      if (fn4) {
+        // 140 VGPRs, three waves per SIMD: one round of resident waves (3 x 1024) per launch
+        int64_t want = std::max<int64_t>(1, 3072 / p.ntiles);
+        if (getenv("BN_REDUCE_CHUNKS")) want = atoi(getenv("BN_REDUCE_CHUNKS"));
+        chunks_r = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, fam.ll_rows_cap), (int64_t)g.nodes.size()));
+        fn = fn4;
+        wide4 = true;
+      }
+    }
+  }
   if (!fn) return -1;
   if (w2 && (w2->chunks != fam.chunks || w.chunks != fam.chunks || w2->chunk_len != fam.chunk_len)) return -1;
   LeafFamilyArgs<T> a;
@@ -676,9 +715,19 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.scaled2 = w2 ? w2->scaled : nullptr;
   a.m_state = static_cast<T*>(fam.m_state);
   a.src = fam.d_src;
-  launch(fn, dim3(wave_blocks((int64_t)fam.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s, arena, cpts, a);
+  int64_t waves = (int64_t)fam.chunks * p.ntiles * leaf_parts(p);
+  if (wide4) {
+    const int32_t K = (int32_t)g.nodes.size();
+    a.chunk_len = (K + chunks_r - 1) / chunks_r;
+    a.chunks = (K + a.chunk_len - 1) / a.chunk_len;
+    a.slots = (int32_t)p.ntiles;
+    waves = (int64_t)a.chunks * p.ntiles;
+  }
+  launch(fn, dim3(wave_blocks(waves)), dim3(256), 0, s, arena, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafReduce) {
+    fam.ll_rows = a.chunks;
+    fam.slots_used = a.slots;
     fam.pending = true;
     fam.pending_fresh = fresh;
     fam.pending_first = first_iteration;
@@ -762,11 +811,11 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
   if (p.dtype == 0) {
     launch(em_finalize_slots<float>, dim3(wave_blocks(items)), dim3(256), 0, s,
            static_cast<const float*>(it->second.em_partial), static_cast<const float*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots, accum);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum);
   } else {
     launch(em_finalize_slots<double>, dim3(wave_blocks(items)), dim3(256), 0, s,
            static_cast<const double*>(it->second.em_partial), static_cast<const double*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots, accum);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum);
   }
   return launch_ok() ? 1 : -1;
 }
