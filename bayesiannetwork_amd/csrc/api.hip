@@ -368,9 +368,19 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
     prof_end(s);
   }
   prof_begin("em_finalize", 0.0, s);
-  bn::launch(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
-                     cpts, p.cpt_total, nchunks, accum);
-  BN_LAUNCH_CHECK("em_finalize");
+  bn::FastState* st = bn::fast_state(p);
+  if (st && !st->fused.empty() && reduced_groups.size() == st->fused.size()) {
+    // every fused group brings its own counts: only the other nodes' entries went through `partial`
+    if (st->n_unfused_entries > 0) {
+      bn::launch(bn::em_finalize_listed<T>, dim3((uint32_t)((st->n_unfused_entries + 255) / 256)), dim3(256), 0, s,
+                 partial, cpts, st->d_unfused_entries, st->n_unfused_entries, nchunks, accum);
+      BN_LAUNCH_CHECK("em_finalize_listed");
+    }
+  } else {
+    bn::launch(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
+                       cpts, p.cpt_total, nchunks, accum);
+    BN_LAUNCH_CHECK("em_finalize");
+  }
   prof_end(s);
   for (const bn::FactorGroup* g : reduced_groups) {
     prof_begin(flabel("em_counts(from leaf_family sums)", *g), 0.0, s);

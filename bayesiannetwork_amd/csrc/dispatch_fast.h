@@ -74,6 +74,10 @@ struct FastState {
   // comes from the families' ll_part rows when their last iteration ran in reduce mode)
   int64_t* d_ll_offs = nullptr;
   int64_t n_ll_offs = 0;
+  // CPT entries of the nodes no fused family serves (the only ones the generic EM sums have to
+  // finalise when every fused group delivers its own counts)
+  int32_t* d_unfused_entries = nullptr;
+  int32_t n_unfused_entries = 0;
   std::vector<WideNode> wide;
   std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
   std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
@@ -136,6 +140,7 @@ inline void release_fast(Plan& p) {
     if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
   if (st->d_ll_offs) (void)hipFree(st->d_ll_offs);
+  if (st->d_unfused_entries) (void)hipFree(st->d_unfused_entries);
   delete st;
   p.fast = nullptr;
 }
@@ -334,6 +339,15 @@ inline int prepare_fast(Plan& p) {
       if (!handled[j]) offs.push_back(p.c_off[j]);
     st.n_ll_offs = (int64_t)offs.size();
     if (!dev_upload(offs, &st.d_ll_offs, p.device_bytes)) return -2;
+    std::vector<int32_t> entries;
+    for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
+      if (st.fused.count((int32_t)fi)) continue;
+      const FactorGroup& g = p.fgroups[fi];
+      for (size_t k = 0; k < g.nodes.size(); ++k)
+        for (int64_t x = 0; x < g.cpt_elems; ++x) entries.push_back((int32_t)(g.cpt_off[k] + x));
+    }
+    st.n_unfused_entries = (int32_t)entries.size();
+    if (!dev_upload(entries, &st.d_unfused_entries, p.device_bytes)) return -2;
   }
   // chunk geometry + scratch
   for (auto& w : st.wide) {

@@ -648,4 +648,17 @@ __global__ void __launch_bounds__(256) em_finalize(const double* __restrict__ pa
   accum[e] = acc * (double)cpts[e];
 }
 
+// The same for a listed subset of the entries (those no fused kernel produces itself).
+template <typename T>
+__global__ void __launch_bounds__(256) em_finalize_listed(const double* __restrict__ partial, const T* __restrict__ cpts,
+                                                         const int32_t* __restrict__ entries, int32_t count,
+                                                         int32_t nchunks, double* __restrict__ accum) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int64_t e = entries[i];
+  double acc = 0.0;
+  for (int32_t c = 0; c < nchunks; ++c) acc += partial[e * nchunks + c];
+  accum[e] = acc * (double)cpts[e];
+}
+
 }  // namespace bn
