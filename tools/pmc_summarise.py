@@ -62,7 +62,8 @@ for name in sorted(set(fetch) | set(write)):
     if m:
         # the ingesting instantiation loads 16 bytes per lane from the caller's arrays (x2 like
         # every such kernel); the others read evidence and loop state 8 bytes per lane
-        factor = 2.0 if int(m.group(4)) // 3 == 3 else LEAF_FACTOR
+        # (and so does the reduce-mode launch with four observations per lane)
+        factor = 2.0 if int(m.group(4)) // 3 == 3 or m.group(3) == "4" else LEAF_FACTOR
     result[short] = dict(
         launches=len(f),
         fetch_correction=factor,
