@@ -95,6 +95,26 @@ struct FastState {
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
 inline FastState* fast_state(const Plan& p) { return static_cast<FastState*>(p.fast); }
 
+// Tuning overrides read once per process (benchmark experiments only):
+//   BN_WIDE_CHUNKS=n    chunks per wide node        BN_REDUCE_CHUNKS=n  chunks of a reduce-mode launch
+//   BN_REDUCE_V2=1      reduce-mode launches with two observations per lane, like the other modes
+inline int32_t env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+inline int32_t env_wide_chunks() {
+  static const int32_t v = env_int("BN_WIDE_CHUNKS");
+  return v;
+}
+inline int32_t env_reduce_chunks() {
+  static const int32_t v = env_int("BN_REDUCE_CHUNKS");
+  return v;
+}
+inline bool env_reduce_v2() {
+  static const bool v = getenv("BN_REDUCE_V2") != nullptr;
+  return v;
+}
+
 inline bool small_dim(int32_t d) {
   switch (d) {
 #define X(V) \
@@ -370,7 +390,7 @@ inline int prepare_fast(Plan& p) {
     // small batches cannot fill the chip anyway; there the combine sets the limit: its waves
     // each walk a share of the chunks, three groups of four at most
     want = std::min<int64_t>(want, 4 * kCombineMaxWaves * 3);
-    if (getenv("BN_WIDE_CHUNKS")) want = atoi(getenv("BN_WIDE_CHUNKS"));
+    if (env_wide_chunks() > 0) want = env_wide_chunks();
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
     // the leaf-family kernel keeps a chunk's exponents in 16 bits
     if (w.fused_fgroup >= 0) chunks = std::max(chunks, (n + kLeafMaxChunkLen - 1) / kLeafMaxChunkLen);
@@ -685,7 +705,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   bool wide4 = false;
   int32_t chunks_r = 0;
   if constexpr (std::is_same<T, float>::value) {
-    if (mode == kLeafReduce && !w2 && g.dims[1] == 2 && p.tile == 256 && !getenv("BN_REDUCE_V2")) {
+    if (mode == kLeafReduce && !w2 && g.dims[1] == 2 && p.tile == 256 && !env_reduce_v2()) {
       LeafFamilyFn<T> fn4 = nullptr;
       switch (state) {
         case kLeafSteady: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafSteady>(g.dims[0]); break;
@@ -695,7 +715,7 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
       if (fn4) {
         // 140 VGPRs, three waves per SIMD: one round of resident waves (3 x 1024) per launch
         int64_t want = std::max<int64_t>(1, 3072 / p.ntiles);
-        if (getenv("BN_REDUCE_CHUNKS")) want = atoi(getenv("BN_REDUCE_CHUNKS"));
+        if (env_reduce_chunks() > 0) want = env_reduce_chunks();
         chunks_r = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, fam.ll_rows_cap), (int64_t)g.nodes.size()));
         fn = fn4;
         wide4 = true;

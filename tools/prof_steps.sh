@@ -7,7 +7,7 @@ python3 - <<PY
 import csv, glob
 f = sorted(glob.glob("$R/gpurun_out/prof_s/*/*kernel_trace.csv"))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "evidence_scatter" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "m_step_rows" in r["Kernel_Name"]]
 for a, b in zip(idx[-8:], idx[-7:]):
     span = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b])
