@@ -871,16 +871,14 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
                                    reduce_last != 2);
     }
   }
-  if constexpr (!std::is_same<T, float>::value) {
-    return 0;
-  } else {
-    float* arena = arena_t;
-    const float* cpts = cpts_t;
+  {
+    T* arena = arena_t;
+    const T* cpts = cpts_t;
     const int32_t K = (int32_t)g.nodes.size();
     const uint32_t blocks = wave_blocks((int64_t)K * p.ntiles);
     if (g.dims.size() == 1) {
       if (st && st->root_written[fi]) return 1;
-      launch(factor_root_fast, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
+      launch(factor_root_fast<T>, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_out, g.d_cpt, K, g.dims[0],
                          p.ntiles);
       if (!launch_ok()) return -1;
       if (st) st->root_written[fi] = 1;
@@ -888,21 +886,23 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
     }
     if (g.dims.size() == 2) {
       const int32_t d0 = g.dims[0], sv = g.dims[1];
-      if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
-        // dense contraction on the matrix cores, one workgroup per (node, tile)
-        const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
-        FactorP1Fn dense = d0 == 64 ? (sv == 64 ? factor_p1_mfma<64, 64> : factor_p1_mfma<64, 32>)
-                                    : (sv == 64 ? factor_p1_mfma<32, 64> : factor_p1_mfma<32, 32>);
-        launch(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
-        return launch_ok() ? 1 : -1;
+      if constexpr (std::is_same<T, float>::value) {
+        if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
+          // dense contraction on the matrix cores, one workgroup per (node, tile)
+          const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
+          FactorP1Fn dense = d0 == 64 ? (sv == 64 ? factor_p1_mfma<64, 64> : factor_p1_mfma<64, 32>)
+                                      : (sv == 64 ? factor_p1_mfma<32, 64> : factor_p1_mfma<32, 32>);
+          launch(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+          return launch_ok() ? 1 : -1;
+        }
       }
-      FactorP1Fn fn = factor_p1_lookup(d0, sv);
+      FactorFn<T> fn = factor_p1_lookup<T>(d0, sv);
       if (!fn) return 0;
       launch(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;
     }
     if (g.dims.size() == 3) {
-      FactorP1Fn fn = factor_p2_lookup(g.dims[0], g.dims[1], g.dims[2]);
+      FactorFn<T> fn = factor_p2_lookup<T>(g.dims[0], g.dims[1], g.dims[2]);
       if (!fn) return 0;
       launch(fn, dim3(blocks), dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
       return launch_ok() ? 1 : -1;

@@ -48,6 +48,36 @@ __device__ __forceinline__ void store4(float* __restrict__ base, int64_t row, in
   *reinterpret_cast<float4*>(base + row * kTile + lane * 4) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
 }
 
+// One message row of a tile as seen by a lane, for either element type: W = 4 floats or 2
+// doubles, 16 bytes per lane either way.
+template <typename T>
+struct rowv {
+  static constexpr int32_t W = tile_of<T>::value / 64;
+  T v[W];
+};
+
+template <typename T>
+__device__ __forceinline__ rowv<T> loadw(const T* __restrict__ base, int64_t row, int32_t lane) {
+  typedef T vec_t __attribute__((ext_vector_type(rowv<T>::W)));
+  const vec_t x = *reinterpret_cast<const vec_t*>(base + row * tile_of<T>::value + lane * rowv<T>::W);
+  rowv<T> r;
+#pragma unroll
+  for (int32_t v = 0; v < rowv<T>::W; ++v) r.v[v] = x[v];
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void storew(T* __restrict__ base, int64_t row, int32_t lane, const rowv<T>& r) {
+  typedef T vec_t __attribute__((ext_vector_type(rowv<T>::W)));
+  vec_t x;
+#pragma unroll
+  for (int32_t v = 0; v < rowv<T>::W; ++v) x[v] = r.v[v];
+  *reinterpret_cast<vec_t*>(base + row * tile_of<T>::value + lane * rowv<T>::W) = x;
+}
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+
 // work item of this wave, or false if past the end.  items = K * ntiles, node-major.
 __device__ __forceinline__ bool wave_item(int64_t items, int64_t ntiles, int32_t& k, int64_t& t, int32_t& lane) {
   // readfirstlane tells the compiler the wave index is uniform: everything derived from it (node,
@@ -65,19 +95,22 @@ __device__ __forceinline__ bool wave_item(int64_t items, int64_t ntiles, int32_t
 // Factor pass, no parent: the message to the variable is the prior itself
 // (FactorNodeGroup._construct_einsum_equation_for_output with no inputs,
 // spa_v3/factor_graph.py:276-284).
-__global__ void __launch_bounds__(256) factor_root_fast(float* __restrict__ arena, const float* __restrict__ cpts,
+template <typename T>
+__global__ void __launch_bounds__(256) factor_root_fast(T* __restrict__ arena, const T* __restrict__ cpts,
                                                        const int64_t* __restrict__ out_off,
                                                        const int64_t* __restrict__ cpt_off, int32_t K, int32_t S,
                                                        int64_t ntiles) {
   int32_t k, lane;
   int64_t t;
   if (!wave_item((int64_t)K * ntiles, ntiles, k, t, lane)) return;
-  float* dst = arena + out_off[k];
-  const float* cpt = cpts + cpt_off[k];
+  T* dst = arena + out_off[k];
+  const T* cpt = cpts + cpt_off[k];
   for (int32_t s = 0; s < S; ++s) {
-    const float c = cpt[s];
-    f4 r{{c, c, c, c}};
-    store4(dst, t * S + s, lane, r);
+    const T c = cpt[s];
+    rowv<T> r;
+#pragma unroll
+    for (int32_t v = 0; v < rowv<T>::W; ++v) r.v[v] = c;
+    storew<T>(dst, t * S + s, lane, r);
   }
 }
 
@@ -86,8 +119,8 @@ __global__ void __launch_bounds__(256) factor_root_fast(float* __restrict__ aren
 //   to parent   out[a] = sum_b cpt[a][b] * in_own[b]
 //   to own var  out[b] = sum_a cpt[a][b] * in_parent[a]
 // (the two einsums of FactorNodeGroup.calculate_outputs, spa_v3/factor_graph.py:251-258).
-template <int D0, int S>
-__global__ void __launch_bounds__(256) factor_p1_fast(float* __restrict__ arena, const float* __restrict__ cpts,
+template <typename T, int D0, int S>
+__global__ void __launch_bounds__(256) factor_p1_fast(T* __restrict__ arena, const T* __restrict__ cpts,
                                                      const int64_t* __restrict__ in_off,
                                                      const int64_t* __restrict__ out_off,
                                                      const int64_t* __restrict__ cpt_off, int32_t K,
@@ -95,51 +128,51 @@ __global__ void __launch_bounds__(256) factor_p1_fast(float* __restrict__ arena,
   int32_t k, lane;
   int64_t t;
   if (!wave_item((int64_t)K * ntiles, ntiles, k, t, lane)) return;
-  const float* in_par = arena + in_off[2 * k];
-  const float* in_own = arena + in_off[2 * k + 1];
-  float* out_par = arena + out_off[2 * k];
-  float* out_own = arena + out_off[2 * k + 1];
-  const float* cpt = cpts + cpt_off[k];
+  const T* in_par = arena + in_off[2 * k];
+  const T* in_own = arena + in_off[2 * k + 1];
+  T* out_par = arena + out_off[2 * k];
+  T* out_own = arena + out_off[2 * k + 1];
+  const T* cpt = cpts + cpt_off[k];
 
-  f4 a[D0], b[S];
+  rowv<T> a[D0], b[S];
 #pragma unroll
-  for (int32_t i = 0; i < D0; ++i) a[i] = load4(in_par, t * D0 + i, lane);
+  for (int32_t i = 0; i < D0; ++i) a[i] = loadw<T>(in_par, t * D0 + i, lane);
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) b[j] = load4(in_own, t * S + j, lane);
+  for (int32_t j = 0; j < S; ++j) b[j] = loadw<T>(in_own, t * S + j, lane);
 
-  f4 oa[D0], ob[S];
+  rowv<T> oa[D0], ob[S];
 #pragma unroll
   for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) oa[i].v[v] = 0.f;
+    for (int32_t v = 0; v < rowv<T>::W; ++v) oa[i].v[v] = T(0);
 #pragma unroll
   for (int32_t j = 0; j < S; ++j)
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) ob[j].v[v] = 0.f;
+    for (int32_t v = 0; v < rowv<T>::W; ++v) ob[j].v[v] = T(0);
 
 #pragma unroll
   for (int32_t i = 0; i < D0; ++i) {
 #pragma unroll
     for (int32_t j = 0; j < S; ++j) {
-      const float c = cpt[i * S + j];
+      const T c = cpt[i * S + j];
 #pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
-        oa[i].v[v] = fmaf(c, b[j].v[v], oa[i].v[v]);
-        ob[j].v[v] = fmaf(c, a[i].v[v], ob[j].v[v]);
+      for (int32_t v = 0; v < rowv<T>::W; ++v) {
+        oa[i].v[v] = fma_t(c, b[j].v[v], oa[i].v[v]);
+        ob[j].v[v] = fma_t(c, a[i].v[v], ob[j].v[v]);
       }
     }
   }
 #pragma unroll
-  for (int32_t i = 0; i < D0; ++i) store4(out_par, t * D0 + i, lane, oa[i]);
+  for (int32_t i = 0; i < D0; ++i) storew<T>(out_par, t * D0 + i, lane, oa[i]);
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) store4(out_own, t * S + j, lane, ob[j]);
+  for (int32_t j = 0; j < S; ++j) storew<T>(out_own, t * S + j, lane, ob[j]);
 }
 
 // ---------------------------------------------------------------------------------
 // Factor pass, two parents (D0, D1) and own variable (S): three contractions of one
 // [D0, D1, S] CPT, each leaving one axis free.
-template <int D0, int D1, int S>
-__global__ void __launch_bounds__(256) factor_p2_fast(float* __restrict__ arena, const float* __restrict__ cpts,
+template <typename T, int D0, int D1, int S>
+__global__ void __launch_bounds__(256) factor_p2_fast(T* __restrict__ arena, const T* __restrict__ cpts,
                                                      const int64_t* __restrict__ in_off,
                                                      const int64_t* __restrict__ out_off,
                                                      const int64_t* __restrict__ cpt_off, int32_t K,
@@ -147,28 +180,28 @@ __global__ void __launch_bounds__(256) factor_p2_fast(float* __restrict__ arena,
   int32_t k, lane;
   int64_t t;
   if (!wave_item((int64_t)K * ntiles, ntiles, k, t, lane)) return;
-  const float* in0 = arena + in_off[3 * k];
-  const float* in1 = arena + in_off[3 * k + 1];
-  const float* in2 = arena + in_off[3 * k + 2];
-  const float* cpt = cpts + cpt_off[k];
+  const T* in0 = arena + in_off[3 * k];
+  const T* in1 = arena + in_off[3 * k + 1];
+  const T* in2 = arena + in_off[3 * k + 2];
+  const T* cpt = cpts + cpt_off[k];
 
-  f4 a[D0], b[D1], c[S];
+  rowv<T> a[D0], b[D1], c[S];
 #pragma unroll
-  for (int32_t i = 0; i < D0; ++i) a[i] = load4(in0, t * D0 + i, lane);
+  for (int32_t i = 0; i < D0; ++i) a[i] = loadw<T>(in0, t * D0 + i, lane);
 #pragma unroll
-  for (int32_t i = 0; i < D1; ++i) b[i] = load4(in1, t * D1 + i, lane);
+  for (int32_t i = 0; i < D1; ++i) b[i] = loadw<T>(in1, t * D1 + i, lane);
 #pragma unroll
-  for (int32_t i = 0; i < S; ++i) c[i] = load4(in2, t * S + i, lane);
+  for (int32_t i = 0; i < S; ++i) c[i] = loadw<T>(in2, t * S + i, lane);
 
-  f4 oa[D0], ob[D1], oc[S];
+  rowv<T> oa[D0], ob[D1], oc[S];
 #pragma unroll
-  for (int32_t v = 0; v < 4; ++v) {
+  for (int32_t v = 0; v < rowv<T>::W; ++v) {
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) oa[i].v[v] = 0.f;
+    for (int32_t i = 0; i < D0; ++i) oa[i].v[v] = T(0);
 #pragma unroll
-    for (int32_t i = 0; i < D1; ++i) ob[i].v[v] = 0.f;
+    for (int32_t i = 0; i < D1; ++i) ob[i].v[v] = T(0);
 #pragma unroll
-    for (int32_t i = 0; i < S; ++i) oc[i].v[v] = 0.f;
+    for (int32_t i = 0; i < S; ++i) oc[i].v[v] = T(0);
   }
 #pragma unroll
   for (int32_t i = 0; i < D0; ++i)
@@ -176,23 +209,23 @@ __global__ void __launch_bounds__(256) factor_p2_fast(float* __restrict__ arena,
     for (int32_t j = 0; j < D1; ++j)
 #pragma unroll
       for (int32_t l = 0; l < S; ++l) {
-        const float w = cpt[(i * D1 + j) * S + l];
+        const T w = cpt[(i * D1 + j) * S + l];
 #pragma unroll
-        for (int32_t v = 0; v < 4; ++v) {
-          oa[i].v[v] = fmaf(w, b[j].v[v] * c[l].v[v], oa[i].v[v]);
-          ob[j].v[v] = fmaf(w, a[i].v[v] * c[l].v[v], ob[j].v[v]);
-          oc[l].v[v] = fmaf(w, a[i].v[v] * b[j].v[v], oc[l].v[v]);
+        for (int32_t v = 0; v < rowv<T>::W; ++v) {
+          oa[i].v[v] = fma_t(w, b[j].v[v] * c[l].v[v], oa[i].v[v]);
+          ob[j].v[v] = fma_t(w, a[i].v[v] * c[l].v[v], ob[j].v[v]);
+          oc[l].v[v] = fma_t(w, a[i].v[v] * b[j].v[v], oc[l].v[v]);
         }
       }
-  float* o0 = arena + out_off[3 * k];
-  float* o1 = arena + out_off[3 * k + 1];
-  float* o2 = arena + out_off[3 * k + 2];
+  T* o0 = arena + out_off[3 * k];
+  T* o1 = arena + out_off[3 * k + 1];
+  T* o2 = arena + out_off[3 * k + 2];
 #pragma unroll
-  for (int32_t i = 0; i < D0; ++i) store4(o0, t * D0 + i, lane, oa[i]);
+  for (int32_t i = 0; i < D0; ++i) storew<T>(o0, t * D0 + i, lane, oa[i]);
 #pragma unroll
-  for (int32_t i = 0; i < D1; ++i) store4(o1, t * D1 + i, lane, ob[i]);
+  for (int32_t i = 0; i < D1; ++i) storew<T>(o1, t * D1 + i, lane, ob[i]);
 #pragma unroll
-  for (int32_t i = 0; i < S; ++i) store4(o2, t * S + i, lane, oc[i]);
+  for (int32_t i = 0; i < S; ++i) storew<T>(o2, t * S + i, lane, oc[i]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -419,27 +452,30 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
 
 #define BN_SMALL_DIMS(X) X(2) X(3) X(4) X(5) X(10)
 
-using FactorP1Fn = void (*)(float*, const float*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t);
+template <typename T>
+using FactorFn = void (*)(T*, const T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t);
+using FactorP1Fn = FactorFn<float>;
 using EmP1Fn = void (*)(const float*, const int64_t*, const int64_t*, int32_t, int64_t, int64_t, int32_t, double*);
 using VarSmallFn = void (*)(float*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t, int32_t);
 
-template <int D0>
-inline FactorP1Fn factor_p1_for_s(int32_t s) {
+template <typename T, int D0>
+inline FactorFn<T> factor_p1_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return factor_p1_fast<D0, SV>;
+    return factor_p1_fast<T, D0, SV>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline FactorP1Fn factor_p1_lookup(int32_t d0, int32_t s) {
+template <typename T>
+inline FactorFn<T> factor_p1_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return factor_p1_for_s<DV>(s);
+    return factor_p1_for_s<T, DV>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
@@ -474,12 +510,12 @@ inline EmP1Fn em_p1_lookup(int32_t d0, int32_t s) {
 #define BN_P2_DIMS(X) X(2) X(3) X(4) X(5)
 constexpr int32_t kP2MaxEntries = 40;
 
-template <int D0, int D1>
-inline FactorP1Fn factor_p2_for_s(int32_t s) {
+template <typename T, int D0, int D1>
+inline FactorFn<T> factor_p2_for_s(int32_t s) {
   switch (s) {
 #define X(SV)                                                          \
   case SV:                                                             \
-    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return factor_p2_fast<D0, D1, SV>; \
+    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return factor_p2_fast<T, D0, D1, SV>; \
     break;
     BN_P2_DIMS(X)
 #undef X
@@ -487,23 +523,24 @@ inline FactorP1Fn factor_p2_for_s(int32_t s) {
   return nullptr;
 }
 
-template <int D0>
-inline FactorP1Fn factor_p2_for_d1(int32_t d1, int32_t s) {
+template <typename T, int D0>
+inline FactorFn<T> factor_p2_for_d1(int32_t d1, int32_t s) {
   switch (d1) {
 #define X(DV) \
   case DV:    \
-    return factor_p2_for_s<D0, DV>(s);
+    return factor_p2_for_s<T, D0, DV>(s);
     BN_P2_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline FactorP1Fn factor_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
+template <typename T>
+inline FactorFn<T> factor_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return factor_p2_for_d1<DV>(d1, s);
+    return factor_p2_for_d1<T, DV>(d1, s);
     BN_P2_DIMS(X)
 #undef X
   }
