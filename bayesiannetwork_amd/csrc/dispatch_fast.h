@@ -573,19 +573,18 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
     }
     return 1;
   }
+  if (g.num_inputs > 4) return 0;
+  if (VarFn<T> fn = var_small_lookup<T>(g.num_inputs, g.num_states)) {
+    // whole node in registers
+    launch(fn, dim3(wave_blocks((int64_t)g.nodes.size() * p.ntiles)), dim3(256), 0, s, arena_t, g.d_in, g.d_out, g.d_c,
+           (int32_t)g.nodes.size(), p.ntiles, fresh);
+    return launch_ok() ? 1 : -1;
+  }
   if constexpr (!std::is_same<T, float>::value) {
     return 0;
   } else {
     float* arena = arena_t;
     const int32_t K = (int32_t)g.nodes.size();
-    if (g.num_inputs > 4) return 0;
-    VarSmallFn fn = g.num_inputs * g.num_states <= 12 ? var_small_lookup(g.num_inputs, g.num_states) : nullptr;
-    if (fn) {
-      // whole node in registers
-      launch(fn, dim3(wave_blocks((int64_t)K * p.ntiles)), dim3(256), 0, s, arena, g.d_in, g.d_out, g.d_c,
-                         K, p.ntiles, fresh);
-      return launch_ok() ? 1 : -1;
-    }
     // 32 or 64 states: the states split over the eight waves of a block, inputs read once
     if ((g.num_states == 32 || g.num_states == 64) && g.num_inputs >= 1 && g.num_inputs <= 4) {
       const dim3 blocks((uint32_t)((int64_t)K * p.ntiles * 2));

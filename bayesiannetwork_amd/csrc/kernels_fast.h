@@ -233,78 +233,154 @@ __global__ void __launch_bounds__(256) factor_p2_fast(T* __restrict__ arena, con
 // P[s] = prod_i in_i[s] fits a double without rescaling (at most four float factors),
 // leave-one-out products are formed by multiplication, not division.
 // Same quantities as variable_pass_generic.
-template <int I, int S>
-__global__ void __launch_bounds__(256) variable_small_fast(float* __restrict__ arena,
+template <typename T, int I, int S>
+__global__ void __launch_bounds__(256) variable_small_fast(T* __restrict__ arena,
                                                           const int64_t* __restrict__ in_off,
                                                           const int64_t* __restrict__ out_off,
                                                           const int64_t* __restrict__ c_off, int32_t K,
                                                           int64_t ntiles, int32_t fresh) {
+  constexpr int32_t W = rowv<T>::W;
   int32_t k, lane;
   int64_t t;
   if (!wave_item((int64_t)K * ntiles, ntiles, k, t, lane)) return;
-  const float uniform = 1.0f / (float)S;
+  const T uniform = T(1) / (T)S;
 
-  f4 in[I][S];
+  rowv<T> in[I][S];
 #pragma unroll
   for (int32_t i = 0; i < I; ++i) {
     const bool skip = fresh && out_off[(int64_t)k * I + i] >= 0;
-    const float* src = arena + in_off[(int64_t)k * I + i];
+    const T* src = arena + in_off[(int64_t)k * I + i];
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
       if (skip) {
-        in[i][s] = f4{{uniform, uniform, uniform, uniform}};
+#pragma unroll
+        for (int32_t v = 0; v < W; ++v) in[i][s].v[v] = uniform;
       } else {
-        in[i][s] = load4(src, t * S + s, lane);
+        in[i][s] = loadw<T>(src, t * S + s, lane);
       }
     }
   }
 
   // leave-one-out products loo[i][s] = prod_{j != i} in_j[s], and the full product
-  double loo[I][S][4];
-  double z[4] = {0.0, 0.0, 0.0, 0.0};
+  double loo[I][S][W];
+  double z[W];
 #pragma unroll
-  for (int32_t s = 0; s < S; ++s) {
-#pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
-      double pre = 1.0;
-#pragma unroll
-      for (int32_t i = 0; i < I; ++i) {
-        loo[i][s][v] = pre;
-        pre *= (double)in[i][s].v[v];
-      }
-      z[v] += pre;
-      double suf = 1.0;
-#pragma unroll
-      for (int32_t i = I - 1; i >= 0; --i) {
-        loo[i][s][v] *= suf;
-        suf *= (double)in[i][s].v[v];
-      }
-    }
-  }
+  for (int32_t v = 0; v < W; ++v) z[v] = 0.0;
 
-  // normaliser c = log sum_s P[s]
-  {
-    f4 c;
+  if constexpr (std::is_same<T, float>::value) {
+    // at most four float factors: the product fits a double as it is
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
-      int e = 0;
-      const double m = frexp(z[v], &e);
-      c.v[v] = (float)((double)e * 0.6931471805599453 + (double)logf((float)m));
+    for (int32_t s = 0; s < S; ++s) {
+#pragma unroll
+      for (int32_t v = 0; v < W; ++v) {
+        double pre = 1.0;
+#pragma unroll
+        for (int32_t i = 0; i < I; ++i) {
+          loo[i][s][v] = pre;
+          pre *= (double)in[i][s].v[v];
+        }
+        z[v] += pre;
+        double suf = 1.0;
+#pragma unroll
+        for (int32_t i = I - 1; i >= 0; --i) {
+          loo[i][s][v] *= suf;
+          suf *= (double)in[i][s].v[v];
+        }
+      }
     }
-    store4(arena + c_off[k], t, lane, c);
+    // normaliser c = log sum_s P[s]
+    {
+      rowv<T> c;
+#pragma unroll
+      for (int32_t v = 0; v < W; ++v) {
+        int e = 0;
+        const double m = frexp(z[v], &e);
+        c.v[v] = (T)((double)e * 0.6931471805599453 + (double)logf((float)m));
+      }
+      storew<T>(arena + c_off[k], t, lane, c);
+    }
+  } else {
+    // double factors can take a plain product out of range (the reference works on logarithms
+    // here, factor_graph.py:114-138): mantissas and exponents are multiplied apart, and every
+    // sum over the states is taken relative to its largest exponent
+    int32_t ex[I][S][W];  // exponent that goes with loo[i][s]
+    int32_t emax[W];
+    double full[S][W];
+    int32_t fex[S][W];
+#pragma unroll
+    for (int32_t v = 0; v < W; ++v) emax[v] = kDeadExponent;
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+#pragma unroll
+      for (int32_t v = 0; v < W; ++v) {
+        double m[I];
+        int32_t e[I];
+#pragma unroll
+        for (int32_t i = 0; i < I; ++i) {
+          int de = 0;
+          m[i] = frexp((double)in[i][s].v[v], &de);
+          e[i] = m[i] == 0.0 ? kDeadExponent : de;
+        }
+        double pre = 1.0;
+        int32_t pre_e = 0;
+#pragma unroll
+        for (int32_t i = 0; i < I; ++i) {
+          loo[i][s][v] = pre;
+          ex[i][s][v] = pre_e;
+          pre *= m[i];
+          pre_e += e[i];
+        }
+        full[s][v] = pre;
+        fex[s][v] = pre_e;
+        emax[v] = pre_e > emax[v] ? pre_e : emax[v];
+        double suf = 1.0;
+        int32_t suf_e = 0;
+#pragma unroll
+        for (int32_t i = I - 1; i >= 0; --i) {
+          loo[i][s][v] *= suf;
+          ex[i][s][v] += suf_e;
+          suf *= m[i];
+          suf_e += e[i];
+        }
+      }
+    }
+    rowv<T> c;
+#pragma unroll
+    for (int32_t v = 0; v < W; ++v) {
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) z[v] += ldexp(full[s][v], clamp_shift(fex[s][v] - emax[v]));
+      c.v[v] = (T)((double)emax[v] * 0.6931471805599453 + log(z[v]));
+    }
+    storew<T>(arena + c_off[k], t, lane, c);
+    // bring every leave-one-out product to a common scale: the local slot shares the full
+    // product's (its message is loo / sum P), the others their own largest exponent
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) {
+#pragma unroll
+      for (int32_t v = 0; v < W; ++v) {
+        int32_t top = emax[v];
+        if (i != I - 1) {
+          top = kDeadExponent;
+#pragma unroll
+          for (int32_t s = 0; s < S; ++s) top = ex[i][s][v] > top ? ex[i][s][v] : top;
+        }
+#pragma unroll
+        for (int32_t s = 0; s < S; ++s) loo[i][s][v] = ldexp(loo[i][s][v], clamp_shift(ex[i][s][v] - top));
+      }
+    }
   }
 
 #pragma unroll
   for (int32_t i = 0; i < I; ++i) {
     const int64_t dst = out_off[(int64_t)k * I + i];
     if (dst < 0) continue;
-    double inv[4];
+    double inv[W];
     if (i == I - 1) {
 #pragma unroll
-      for (int32_t v = 0; v < 4; ++v) inv[v] = 1.0 / z[v];
+      for (int32_t v = 0; v < W; ++v) inv[v] = 1.0 / z[v];
     } else {
 #pragma unroll
-      for (int32_t v = 0; v < 4; ++v) {
+      for (int32_t v = 0; v < W; ++v) {
         double sum = 0.0;
 #pragma unroll
         for (int32_t s = 0; s < S; ++s) sum += loo[i][s][v];
@@ -313,10 +389,10 @@ __global__ void __launch_bounds__(256) variable_small_fast(float* __restrict__ a
     }
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
-      f4 o;
+      rowv<T> o;
 #pragma unroll
-      for (int32_t v = 0; v < 4; ++v) o.v[v] = (float)(loo[i][s][v] * inv[v]);
-      store4(arena + dst, t * S + s, lane, o);
+      for (int32_t v = 0; v < W; ++v) o.v[v] = (T)(loo[i][s][v] * inv[v]);
+      storew<T>(arena + dst, t * S + s, lane, o);
     }
   }
 }
@@ -456,7 +532,9 @@ template <typename T>
 using FactorFn = void (*)(T*, const T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t);
 using FactorP1Fn = FactorFn<float>;
 using EmP1Fn = void (*)(const float*, const int64_t*, const int64_t*, int32_t, int64_t, int64_t, int32_t, double*);
-using VarSmallFn = void (*)(float*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t, int32_t);
+template <typename T>
+using VarFn = void (*)(T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t, int32_t);
+using VarSmallFn = VarFn<float>;
 
 template <typename T, int D0>
 inline FactorFn<T> factor_p1_for_s(int32_t s) {
@@ -594,28 +672,31 @@ inline EmP1Fn em_root_lookup(int32_t s) {
   return nullptr;
 }
 
-template <int I>
-inline VarSmallFn var_small_for_s(int32_t s) {
+template <typename T, int I>
+inline VarFn<T> var_small_for_s(int32_t s) {
   switch (s) {
-#define X(SV) \
-  case SV:    \
-    return variable_small_fast<I, SV>;
+#define X(SV)                                                        \
+  case SV:                                                           \
+    if constexpr (I * SV <= 12) return variable_small_fast<T, I, SV>; \
+    break;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline VarSmallFn var_small_lookup(int32_t fan_in, int32_t s) {
+// whole node in registers: fan-in up to 4 and at most 12 message entries per observation
+template <typename T>
+inline VarFn<T> var_small_lookup(int32_t fan_in, int32_t s) {
   switch (fan_in) {
     case 1:
-      return var_small_for_s<1>(s);
+      return var_small_for_s<T, 1>(s);
     case 2:
-      return var_small_for_s<2>(s);
+      return var_small_for_s<T, 2>(s);
     case 3:
-      return var_small_for_s<3>(s);
+      return var_small_for_s<T, 3>(s);
     case 4:
-      return var_small_for_s<4>(s);
+      return var_small_for_s<T, 4>(s);
   }
   return nullptr;
 }
