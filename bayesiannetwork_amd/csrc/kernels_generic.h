@@ -50,13 +50,21 @@ __device__ __forceinline__ int64_t msg_index(int64_t base, int64_t tile_id, int3
 //
 // The reference evaluates these through log / sum / softmax / exp to survive underflow.
 // Here the product is carried as a double mantissa plus an integer exponent per state
-// (renormalised every four factors), which is the same quantity without any
+// (renormalised every four float factors, every double factor), which is the same quantity without any
 // transcendental and without the ~1e-7*|log| rounding that a float32 sum of several
 // hundred logs picks up.  An exactly-zero input gives P = 0 and 0/0 = NaN on its own
 // outgoing message and 0 on the others, as -inf - -inf does in the reference.
 //
 // grid.x = K * ntiles * (tile / 64), block = 64, dynamic LDS = S*64*24 bytes.
 constexpr int32_t kDeadExponent = -(1 << 28);
+
+// A running product kept as a double is brought back to [0.5, 1) before it can leave the double
+// range: four float factors always fit (each >= 2^-149), a single double factor may already be
+// close to the limit.
+template <typename T>
+__device__ __forceinline__ bool renorm_due(int32_t factors_done) {
+  return sizeof(T) == 8 ? true : (factors_done & 3) == 0;
+}
 
 __device__ __forceinline__ int32_t clamp_shift(int32_t e) { return e < -4000 ? -4000 : (e > 4000 ? 4000 : e); }
 
@@ -100,7 +108,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
     int32_t e = 0;
     for (int32_t i = 0; i < I; ++i) {
       m *= (double)input(i, s);
-      if ((i & 3) == 3 || i == I - 1) {
+      if (renorm_due<T>(i + 1) || i == I - 1) {
         int de = 0;
         m = frexp(m, &de);
         e += de;

@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
         for (int32_t i = 0; i < D0; ++i) pm[i][v] *= (double)q[i][v];
         pz[v] *= (double)cur.z[v];
       }
-      if (((k - first) & 3) == 3) {
+      if (renorm_due<T>(k - first + 1)) {
 #pragma unroll
         for (int32_t i = 0; i < D0; ++i) {
           ev_t<V> de_v;
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       // sum_k log z_k = log prod_k z_k: the product is carried like in loop mode, one log at the end
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) pz[v] *= (double)cur.z[v];
-      if (((k - first) & 3) == 3) {
+      if (renorm_due<T>(k - first + 1)) {
 #pragma unroll
         for (int32_t v = 0; v < V; ++v) {
           int de = 0;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) pm[i][v] *= (double)new_par[i][v];
-    if (((k - first) & 3) == 3) {
+    if (renorm_due<T>(k - first + 1)) {
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
         ev_t<V> de_v;
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) wide_product_any(const T* __restrict__ ar
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) m[s][v] *= (double)x[v];
     }
-    if (((j - first) & 3) == 3 || j + 1 == last) {
+    if (renorm_due<T>(j - first + 1) || j + 1 == last) {
 #pragma unroll
       for (int32_t s = 0; s < S; ++s)
 #pragma unroll
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
 #pragma unroll
       for (int32_t i = 0; i < D1; ++i) pm2[i][v] *= (double)m2[i][v];
     }
-    if (((k - first) & 3) == 3) {
+    if (renorm_due<T>(k - first + 1)) {
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
 #pragma unroll

@@ -227,3 +227,50 @@ def test_iteration_stops_when_the_normalisers_settle_and_callbacks_can_query(nam
     for j, node in enumerate(network.nodes):
         np.testing.assert_allclose(machine.infer_single_nodes([node])[0].cpu().double().numpy(),
                                    oracle.infer_single(j).numpy(), rtol=2e-4 if f32 else 1e-8, atol=1e-7 if f32 else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_children", [3, 10, 40])
+@pytest.mark.parametrize("dtype,tiny", [("float64", 1e-100), ("float32", 1e-30)])
+def test_products_that_leave_the_floating_point_range(num_children, dtype, tiny):
+    """The reference's HandleNumericalUnderflow case (torch_inference_machine_generic_tests.py:1088-1192):
+    every child contradicts its evidence with probability `tiny`, so the root's product of messages
+    is tiny^num_children — far below the element type's range.  No NaN anywhere, and the results
+    equal the CPU oracle's (which works on logarithms like the reference).  3 children take the
+    register-resident variable kernel, 10 the generic one, 40 the wide-parent / leaf-family path."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+    from oracle.spa_oracle import SpaOracle
+
+    n = 2
+
+    def build(device):
+        ts = TorchSettings(device=device, dtype=dtype)
+        q = Node(torch.tensor([0.5, 0.5], device=ts.device, dtype=ts.dtype), name="Q")
+        ys = [Node(torch.tensor([[tiny, 1 - tiny], [tiny, 1 - tiny]], device=ts.device, dtype=ts.dtype), name=f"Y{i}")
+              for i in range(num_children)]
+        builder = BayesianNetworkBuilder().add_node(q)
+        for y in ys:
+            builder.add_node(y, parents=q)
+        rows = [torch.tensor([[1 - tiny, tiny]], dtype=ts.dtype).repeat((n, 1)) for _ in ys]
+        return ts, builder.build(), q, ys, rows
+
+    ts, network, q, ys, rows = build("cuda")
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, ys, n)
+    machine.enter_evidence(Evidence([r.to("cuda") for r in rows], ts))
+    _, network_cpu, q_cpu, ys_cpu, _ = build("cpu")
+    oracle = SpaOracle(network_cpu, ys_cpu, n, dtype=ts.dtype)
+    oracle.enter_evidence(rows)
+
+    ll = machine.log_likelihood()
+    assert np.isfinite(ll)
+    want_ll = oracle.log_likelihood(False)
+    assert abs(ll - want_ll) <= (1e-9 if dtype == "float64" else 1e-5) * abs(want_ll)
+    nodes = list(network.nodes)
+    tol = 1e-9 if dtype == "float64" else 1e-5
+    for j, (got, fam) in enumerate(zip(machine.infer_single_nodes(nodes), machine.infer_nodes_with_parents(nodes))):
+        assert not got.isnan().any() and not fam.isnan().any(), nodes[j].name
+        np.testing.assert_allclose(got.cpu().double().numpy(), oracle.infer_single(j).double().numpy(), rtol=tol, atol=1e-12)
+        np.testing.assert_allclose(fam.cpu().double().numpy(), oracle.infer_family(j).double().numpy(), rtol=tol, atol=1e-12)
