@@ -54,7 +54,9 @@ def _draw(seed):
     for j in observed:
         s = cards[j]
         soft = torch.rand((n, s), generator=gen, dtype=torch.float64) + 1e-3
-        hard = torch.nn.functional.one_hot(torch.randint(0, s, (n,), generator=gen), s).double() * (1 - 1e-6) + 1e-6 / max(s, 1)
+        hard = torch.nn.functional.one_hot(torch.randint(0, s, (n,), generator=gen), s).double()
+        if seed % 4 != 2:  # soft-clamped like the reference's experiments; exact zeros and ones otherwise (its docs)
+            hard = hard * (1 - 1e-6) + 1e-6 / max(s, 1)
         pick = (torch.rand((n, 1), generator=gen) < 0.5).double()
         evidence.append(pick * hard + (1 - pick) * soft / soft.sum(-1, keepdim=True))
     return spec, observed, evidence, n, loopy
