@@ -911,41 +911,30 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
 }
 
 template <typename T>
-int launch_em_fast(Plan& p, FactorGroup& g, const T* arena_t, int32_t nchunks, double* partial, hipStream_t s) {
-  if constexpr (!std::is_same<T, float>::value) {
-    return 0;
-  } else {
-    const float* arena = arena_t;
-    const int32_t K = (int32_t)g.nodes.size();
-    const uint32_t blocks = wave_blocks((int64_t)K * nchunks);
-    if (g.dims.size() == 1) {
-      EmP1Fn fn = em_root_lookup(g.dims[0]);
-      if (!fn) return 0;
-      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
-      return launch_ok() ? 1 : -1;
-    }
-    if (g.dims.size() == 2) {
-      const int32_t d0 = g.dims[0], sv = g.dims[1];
+int launch_em_fast(Plan& p, FactorGroup& g, const T* arena, int32_t nchunks, double* partial, hipStream_t s) {
+  const int32_t K = (int32_t)g.nodes.size();
+  const uint32_t blocks = wave_blocks((int64_t)K * nchunks);
+  EmFn<T> fn = nullptr;
+  if (g.dims.size() == 1) {
+    fn = em_root_lookup<T>(g.dims[0]);
+  } else if (g.dims.size() == 2) {
+    const int32_t d0 = g.dims[0], sv = g.dims[1];
+    if constexpr (std::is_same<T, float>::value) {
       if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
         EmP1Fn dense = d0 == 64 ? (sv == 64 ? em_p1_mfma<64, 64> : em_p1_mfma<64, 32>)
                                 : (sv == 64 ? em_p1_mfma<32, 64> : em_p1_mfma<32, 32>);
         launch(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
-                           p.ntiles, nchunks, partial);
+               p.ntiles, nchunks, partial);
         return launch_ok() ? 1 : -1;
       }
-      EmP1Fn fn = em_p1_lookup(g.dims[0], g.dims[1]);
-      if (!fn) return 0;
-      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
-      return launch_ok() ? 1 : -1;
     }
-    if (g.dims.size() == 3) {
-      EmP1Fn fn = em_p2_lookup(g.dims[0], g.dims[1], g.dims[2]);
-      if (!fn) return 0;
-      launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
-      return launch_ok() ? 1 : -1;
-    }
-    return 0;
+    fn = em_p1_lookup<T>(d0, sv);
+  } else if (g.dims.size() == 3) {
+    fn = em_p2_lookup<T>(g.dims[0], g.dims[1], g.dims[2]);
   }
+  if (!fn) return 0;
+  launch(fn, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial);
+  return launch_ok() ? 1 : -1;
 }
 
 }  // namespace bn

@@ -402,8 +402,8 @@ __global__ void __launch_bounds__(256) variable_small_fast(T* __restrict__ arena
 // parent message is the constant 1): per lane running sums of in_parent[a] * in_own[b]
 // over the observations of the wave's tile range (double running sums), then a wave reduction.  The CPT factor
 // and the sum over chunks are applied by em_finalize.
-template <int D0, int S, bool HAS_PARENT>
-__global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
+template <typename T, int D0, int S, bool HAS_PARENT>
+__global__ void __launch_bounds__(256) em_p1_fast(const T* __restrict__ arena, const int64_t* __restrict__ in_off,
                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
                                                  int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
   const int32_t k = (int32_t)(w / nchunks);
   const int32_t chunk = (int32_t)(w % nchunks);
   constexpr int32_t A = HAS_PARENT ? 2 : 1;
-  const float* in_par = HAS_PARENT ? arena + in_off[(int64_t)k * A] : nullptr;
-  const float* in_own = arena + in_off[(int64_t)k * A + (A - 1)];
+  const T* in_par = HAS_PARENT ? arena + in_off[(int64_t)k * A] : nullptr;
+  const T* in_own = arena + in_off[(int64_t)k * A + (A - 1)];
 
   const int64_t per = (ntiles + nchunks - 1) / nchunks;
   const int64_t t0 = chunk * per;
@@ -426,20 +426,23 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
     for (int32_t j = 0; j < S; ++j) acc[i][j] = 0.0;
 
   for (int64_t t = t0; t < t1; ++t) {
-    f4 a[D0], b[S];
+    rowv<T> a[D0], b[S];
 #pragma unroll
     for (int32_t i = 0; i < D0; ++i) {
       if (HAS_PARENT) {
-        a[i] = load4(in_par, t * D0 + i, lane);
+        a[i] = loadw<T>(in_par, t * D0 + i, lane);
       } else {
-        a[i] = f4{{1.f, 1.f, 1.f, 1.f}};
+        {
+#pragma unroll
+          for (int32_t v = 0; v < rowv<T>::W; ++v) a[i].v[v] = T(1);
+        }
       }
     }
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) b[j] = load4(in_own, t * S + j, lane);
-    const int64_t n0 = t * kTile + lane * 4;
+    for (int32_t j = 0; j < S; ++j) b[j] = loadw<T>(in_own, t * S + j, lane);
+    const int64_t n0 = t * tile_of<T>::value + lane * rowv<T>::W;
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
+    for (int32_t v = 0; v < rowv<T>::W; ++v) {
       const double live = (n0 + v < N) ? 1.0 : 0.0;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
@@ -460,8 +463,8 @@ __global__ void __launch_bounds__(256) em_p1_fast(const float* __restrict__ aren
     }
 }
 
-template <int D0, int D1, int S>
-__global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ arena, const int64_t* __restrict__ in_off,
+template <typename T, int D0, int D1, int S>
+__global__ void __launch_bounds__(256) em_p2_fast(const T* __restrict__ arena, const int64_t* __restrict__ in_off,
                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
                                                  int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -469,9 +472,9 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
   if (w >= (int64_t)K * nchunks) return;
   const int32_t k = (int32_t)(w / nchunks);
   const int32_t chunk = (int32_t)(w % nchunks);
-  const float* in0 = arena + in_off[(int64_t)k * 3];
-  const float* in1 = arena + in_off[(int64_t)k * 3 + 1];
-  const float* in2 = arena + in_off[(int64_t)k * 3 + 2];
+  const T* in0 = arena + in_off[(int64_t)k * 3];
+  const T* in1 = arena + in_off[(int64_t)k * 3 + 1];
+  const T* in2 = arena + in_off[(int64_t)k * 3 + 2];
 
   const int64_t per = (ntiles + nchunks - 1) / nchunks;
   const int64_t t0 = chunk * per;
@@ -486,16 +489,16 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
       for (int32_t l = 0; l < S; ++l) acc[i][j][l] = 0.0;
 
   for (int64_t t = t0; t < t1; ++t) {
-    f4 a[D0], b[D1], c[S];
+    rowv<T> a[D0], b[D1], c[S];
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) a[i] = load4(in0, t * D0 + i, lane);
+    for (int32_t i = 0; i < D0; ++i) a[i] = loadw<T>(in0, t * D0 + i, lane);
 #pragma unroll
-    for (int32_t i = 0; i < D1; ++i) b[i] = load4(in1, t * D1 + i, lane);
+    for (int32_t i = 0; i < D1; ++i) b[i] = loadw<T>(in1, t * D1 + i, lane);
 #pragma unroll
-    for (int32_t i = 0; i < S; ++i) c[i] = load4(in2, t * S + i, lane);
-    const int64_t n0 = t * kTile + lane * 4;
+    for (int32_t i = 0; i < S; ++i) c[i] = loadw<T>(in2, t * S + i, lane);
+    const int64_t n0 = t * tile_of<T>::value + lane * rowv<T>::W;
 #pragma unroll
-    for (int32_t v = 0; v < 4; ++v) {
+    for (int32_t v = 0; v < rowv<T>::W; ++v) {
       const double live = (n0 + v < N) ? 1.0 : 0.0;
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
@@ -531,7 +534,9 @@ __global__ void __launch_bounds__(256) em_p2_fast(const float* __restrict__ aren
 template <typename T>
 using FactorFn = void (*)(T*, const T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t);
 using FactorP1Fn = FactorFn<float>;
-using EmP1Fn = void (*)(const float*, const int64_t*, const int64_t*, int32_t, int64_t, int64_t, int32_t, double*);
+template <typename T>
+using EmFn = void (*)(const T*, const int64_t*, const int64_t*, int32_t, int64_t, int64_t, int32_t, double*);
+using EmP1Fn = EmFn<float>;
 template <typename T>
 using VarFn = void (*)(T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t, int32_t);
 using VarSmallFn = VarFn<float>;
@@ -560,23 +565,24 @@ inline FactorFn<T> factor_p1_lookup(int32_t d0, int32_t s) {
   return nullptr;
 }
 
-template <int D0>
-inline EmP1Fn em_p1_for_s(int32_t s) {
+template <typename T, int D0>
+inline EmFn<T> em_p1_for_s(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return em_p1_fast<D0, SV, true>;
+    return em_p1_fast<T, D0, SV, true>;
     BN_SMALL_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline EmP1Fn em_p1_lookup(int32_t d0, int32_t s) {
+template <typename T>
+inline EmFn<T> em_p1_lookup(int32_t d0, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return em_p1_for_s<DV>(s);
+    return em_p1_for_s<T, DV>(s);
     BN_SMALL_DIMS(X)
 #undef X
   }
@@ -625,12 +631,12 @@ inline FactorFn<T> factor_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
   return nullptr;
 }
 
-template <int D0, int D1>
-inline EmP1Fn em_p2_for_s(int32_t s) {
+template <typename T, int D0, int D1>
+inline EmFn<T> em_p2_for_s(int32_t s) {
   switch (s) {
 #define X(SV)                                                      \
   case SV:                                                         \
-    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return em_p2_fast<D0, D1, SV>; \
+    if constexpr (D0 * D1 * SV <= kP2MaxEntries) return em_p2_fast<T, D0, D1, SV>; \
     break;
     BN_P2_DIMS(X)
 #undef X
@@ -638,34 +644,36 @@ inline EmP1Fn em_p2_for_s(int32_t s) {
   return nullptr;
 }
 
-template <int D0>
-inline EmP1Fn em_p2_for_d1(int32_t d1, int32_t s) {
+template <typename T, int D0>
+inline EmFn<T> em_p2_for_d1(int32_t d1, int32_t s) {
   switch (d1) {
 #define X(DV) \
   case DV:    \
-    return em_p2_for_s<D0, DV>(s);
+    return em_p2_for_s<T, D0, DV>(s);
     BN_P2_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline EmP1Fn em_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
+template <typename T>
+inline EmFn<T> em_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return em_p2_for_d1<DV>(d1, s);
+    return em_p2_for_d1<T, DV>(d1, s);
     BN_P2_DIMS(X)
 #undef X
   }
   return nullptr;
 }
 
-inline EmP1Fn em_root_lookup(int32_t s) {
+template <typename T>
+inline EmFn<T> em_root_lookup(int32_t s) {
   switch (s) {
 #define X(SV) \
   case SV:    \
-    return em_p1_fast<1, SV, false>;
+    return em_p1_fast<T, 1, SV, false>;
     BN_SMALL_DIMS(X)
 #undef X
   }
