@@ -1,11 +1,14 @@
-// Shape-specialised float32 kernels for the shapes that carry the throughput.
+// Shape-specialised kernels for the shapes that carry the throughput.
 //
-// Common structure: one wavefront owns one (node, tile) work item — 256 observations,
-// four per lane — and moves every message row with one 16-byte load/store per lane
-// (1 KiB per wave instruction, fully coalesced).  Cardinalities and fan-in are template
-// parameters, so all per-lane vectors live in registers and every loop unrolls; CPT
-// entries are wave-uniform and arrive through scalar loads.  All of these kernels stream
-// each input once and each output once: they are HBM-bandwidth bound by construction.
+// Common structure: one wavefront owns one (node, tile) work item and moves every message row
+// with one 16-byte load/store per lane (1 KiB per wave instruction, fully coalesced): a tile is 256
+// float32 observations, four per lane, or 128 float64 observations, two per lane.  Cardinalities
+// and fan-in are template parameters, so all per-lane vectors live in registers and every loop
+// unrolls; CPT entries are wave-uniform and arrive through scalar loads.  All of these kernels
+// stream each input once and each output once: they are HBM-bandwidth bound by construction.
+// The register-resident variable pass, the small factor kernels and their EM count kernels are
+// templates over the element type; the many-state kernels (kernels_dense.h) and the standalone
+// wide-node kernels (kernels_wide.h) exist for float32 only.
 //
 // Each launch_* helper returns 1 if it handled the group, 0 if the caller must use the
 // generic kernel, and a negative value on a launch failure.
@@ -530,6 +533,8 @@ __global__ void __launch_bounds__(256) em_p2_fast(const T* __restrict__ arena, c
 // =================================================================================
 
 #define BN_SMALL_DIMS(X) X(2) X(3) X(4) X(5) X(10)
+// cardinalities of the one-parent factor and EM count kernels (cheap to instantiate densely)
+#define BN_P1_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 
 template <typename T>
 using FactorFn = void (*)(T*, const T*, const int64_t*, const int64_t*, const int64_t*, int32_t, int64_t);
@@ -547,7 +552,7 @@ inline FactorFn<T> factor_p1_for_s(int32_t s) {
 #define X(SV) \
   case SV:    \
     return factor_p1_fast<T, D0, SV>;
-    BN_SMALL_DIMS(X)
+    BN_P1_DIMS(X)
 #undef X
   }
   return nullptr;
@@ -559,7 +564,7 @@ inline FactorFn<T> factor_p1_lookup(int32_t d0, int32_t s) {
 #define X(DV) \
   case DV:    \
     return factor_p1_for_s<T, DV>(s);
-    BN_SMALL_DIMS(X)
+    BN_P1_DIMS(X)
 #undef X
   }
   return nullptr;
@@ -571,7 +576,7 @@ inline EmFn<T> em_p1_for_s(int32_t s) {
 #define X(SV) \
   case SV:    \
     return em_p1_fast<T, D0, SV, true>;
-    BN_SMALL_DIMS(X)
+    BN_P1_DIMS(X)
 #undef X
   }
   return nullptr;
@@ -583,7 +588,7 @@ inline EmFn<T> em_p1_lookup(int32_t d0, int32_t s) {
 #define X(DV) \
   case DV:    \
     return em_p1_for_s<T, DV>(s);
-    BN_SMALL_DIMS(X)
+    BN_P1_DIMS(X)
 #undef X
   }
   return nullptr;
@@ -674,7 +679,7 @@ inline EmFn<T> em_root_lookup(int32_t s) {
 #define X(SV) \
   case SV:    \
     return em_p1_fast<T, 1, SV, false>;
-    BN_SMALL_DIMS(X)
+    BN_P1_DIMS(X)
 #undef X
   }
   return nullptr;
