@@ -372,7 +372,7 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
   if (st && !st->fused.empty() && reduced_groups.size() == st->fused.size()) {
     // every fused group brings its own counts: only the other nodes' entries went through `partial`
     if (st->n_unfused_entries > 0) {
-      bn::launch(bn::em_finalize_listed<T>, dim3((uint32_t)((st->n_unfused_entries + 255) / 256)), dim3(256), 0, s,
+      bn::launch(bn::em_finalize_listed<T>, dim3((uint32_t)((st->n_unfused_entries + 3) / 4)), dim3(256), 0, s,
                  partial, cpts, st->d_unfused_entries, st->n_unfused_entries, nchunks, accum);
       BN_LAUNCH_CHECK("em_finalize_listed");
     }

@@ -656,17 +656,23 @@ __global__ void __launch_bounds__(256) em_finalize(const double* __restrict__ pa
   accum[e] = acc * (double)cpts[e];
 }
 
-// The same for a listed subset of the entries (those no fused kernel produces itself).
+// The same for a listed subset of the entries (those no fused kernel produces itself), one wave
+// per entry: the chunk partials of an entry are contiguous, and there are few entries but many
+// chunks when only a handful of nodes go through the partial sums.
+//   grid.x = ceil(count / 4), block = 256
 template <typename T>
 __global__ void __launch_bounds__(256) em_finalize_listed(const double* __restrict__ partial, const T* __restrict__ cpts,
                                                          const int32_t* __restrict__ entries, int32_t count,
                                                          int32_t nchunks, double* __restrict__ accum) {
-  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  const int32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= count) return;
   const int64_t e = entries[i];
+  // fixed association: lane l sums chunks l, l + 64, ..; then the butterfly
   double acc = 0.0;
-  for (int32_t c = 0; c < nchunks; ++c) acc += partial[e * nchunks + c];
-  accum[e] = acc * (double)cpts[e];
+  for (int32_t c = lane; c < nchunks; c += 64) acc += partial[e * nchunks + c];
+#pragma unroll
+  for (int32_t off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) accum[e] = acc * (double)cpts[e];
 }
 
 }  // namespace bn
