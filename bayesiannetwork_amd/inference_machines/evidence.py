@@ -122,9 +122,38 @@ class PrefetchingLoader:
         moved = Evidence.__new__(Evidence)
         moved.torch_settings = ts
         moved.num_observed_nodes, moved.num_observations = batch.num_observed_nodes, batch.num_observations
+        base = self._common_base(batch.data)
+        if base is not None:
+            # all tensors are consecutive slices of one host buffer (torch.stack(...).unbind(0), the
+            # usual product of an evidence transform): one large copy instead of one per observed node
+            base = base if base.is_pinned() else base.pin_memory()
+            whole = base.to(self._device, ts.dtype, non_blocking=True)
+            moved._data, pos = [], 0
+            for d in batch.data:
+                moved._data.append(whole[pos : pos + d.numel()].view(d.shape))
+                pos += d.numel()
+            return moved
         moved._data = [(d if d.is_pinned() or d.is_cuda else d.pin_memory()).to(self._device, ts.dtype, non_blocking=True)
                        for d in batch.data]
         return moved
+
+    @staticmethod
+    def _common_base(tensors):
+        """The flat host tensor that ``tensors`` tile back to back, or None."""
+        first = tensors[0]
+        if first.is_cuda or not first.is_contiguous():
+            return None
+        storage_ptr = first.untyped_storage().data_ptr()
+        start, pos = first.storage_offset(), first.storage_offset()
+        for t in tensors:
+            if (t.is_cuda or t.dtype != first.dtype or not t.is_contiguous() or t.storage_offset() != pos
+                    or t.untyped_storage().data_ptr() != storage_ptr):
+                return None
+            pos += t.numel()
+        if len(tensors) < 2:
+            return None
+        flat = torch.empty(0, dtype=first.dtype).set_(first.untyped_storage(), start, (pos - start,))
+        return flat
 
     def __iter__(self):
         if self._device.type != "cuda":

@@ -235,7 +235,8 @@ def main():
                 hard.states = hard.states.pin_memory()
                 host_batches.append(hard)
             else:
-                host_batches.append(Evidence([d.cpu().pin_memory() for d in b.data], host_ts))
+                # one pinned buffer [observed nodes, n, states], the tensors are its slices
+                host_batches.append(Evidence(list(torch.stack(b.data).cpu().pin_memory().unbind(0)), host_ts))
 
     def run(steps):
         if host_batches is not None:

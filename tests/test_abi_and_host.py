@@ -174,3 +174,24 @@ def test_hard_evidence_stands_for_its_one_hot_tensors():
     batches = [hard[0:4], hard[4:8], hard[8:11]]
     assert [b is c for b, c in zip(PrefetchingLoader(batches, "cpu"), batches)] == [True, True, True]
     assert len(PrefetchingLoader(batches, "cpu")) == 3
+
+
+def test_prefetching_loader_recognises_evidence_that_tiles_one_host_buffer():
+    """torch.stack(...).unbind(0) evidence goes to the device as one copy; separately allocated
+    tensors, a gap, or a permuted order do not qualify."""
+    import torch
+
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, PrefetchingLoader
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cpu", dtype="float32")
+    x = torch.rand(5, 7, 2)
+    tiled = Evidence(list(x.unbind(0)), ts)
+    base = PrefetchingLoader._common_base(tiled.data)
+    assert base is not None and base.numel() == 70 and torch.equal(base.view(5, 7, 2), x)
+    inner = Evidence(list(x[1:4].unbind(0)), ts)  # a window into a larger buffer
+    base = PrefetchingLoader._common_base(inner.data)
+    assert base is not None and torch.equal(base.view(3, 7, 2), x[1:4])
+    assert PrefetchingLoader._common_base(Evidence([torch.rand(7, 2) for _ in range(3)], ts).data) is None
+    assert PrefetchingLoader._common_base(Evidence([x[0], x[2], x[3]], ts).data) is None
+    assert PrefetchingLoader._common_base(Evidence([x[1], x[0]], ts).data) is None
