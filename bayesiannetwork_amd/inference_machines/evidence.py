@@ -17,6 +17,42 @@ import torch
 from ..torch_settings import TorchSettings
 
 
+def _common_base(tensors):
+    """The flat host tensor that ``tensors`` tile back to back, or None."""
+    first = tensors[0]
+    if first.is_cuda or not first.is_contiguous():
+        return None
+    storage_ptr = first.untyped_storage().data_ptr()
+    start, pos = first.storage_offset(), first.storage_offset()
+    for t in tensors:
+        if (t.is_cuda or t.dtype != first.dtype or not t.is_contiguous() or t.storage_offset() != pos
+                or t.untyped_storage().data_ptr() != storage_ptr):
+            return None
+        pos += t.numel()
+    if len(tensors) < 2:
+        return None
+    return torch.empty(0, dtype=first.dtype).set_(first.untyped_storage(), start, (pos - start,))
+
+
+def _to_device(tensors, device, dtype, non_blocking=False, pin=False):
+    """``[t.to(device, dtype) for t in tensors]``; host tensors that tile one buffer (the product of
+    ``torch.stack(...).unbind(0)`` in an evidence transform) cross to the device as one copy."""
+    device = torch.device(device)
+    base = _common_base(tensors) if device.type == "cuda" else None
+    if base is not None:
+        if pin and not base.is_pinned():
+            base = base.pin_memory()
+        whole = base.to(device, dtype, non_blocking=non_blocking)
+        out, pos = [], 0
+        for t in tensors:
+            out.append(whole[pos : pos + t.numel()].view(t.shape))
+            pos += t.numel()
+        return out
+    if pin:
+        tensors = [t if t.is_pinned() or t.is_cuda else t.pin_memory() for t in tensors]
+    return [t.to(device, dtype, non_blocking=non_blocking) for t in tensors]
+
+
 class Evidence:
     def __init__(self, data: Sequence[torch.Tensor], torch_settings: TorchSettings):
         self.torch_settings = torch_settings
@@ -26,9 +62,7 @@ class Evidence:
             assert d.shape[0] == self.num_observations, (
                 "Number of observations not equal for each observed node"
             )
-        self._data: List[torch.Tensor] = [
-            d.to(torch_settings.device, torch_settings.dtype) for d in data
-        ]
+        self._data: List[torch.Tensor] = _to_device(list(data), torch_settings.device, torch_settings.dtype)
 
     @property
     def data(self) -> List[torch.Tensor]:
@@ -93,6 +127,7 @@ class HardEvidence(Evidence):
 
 
 class PrefetchingLoader:
+    _common_base = staticmethod(_common_base)
     """Wraps an iterable of evidence batches that live in host memory and moves batch k+1 to the
     device (pinned staging buffer, side stream) while batch k is being used, so that a training
     loop never waits for a host-to-device copy it could have overlapped.  ``to_device`` maps a host
@@ -122,38 +157,8 @@ class PrefetchingLoader:
         moved = Evidence.__new__(Evidence)
         moved.torch_settings = ts
         moved.num_observed_nodes, moved.num_observations = batch.num_observed_nodes, batch.num_observations
-        base = self._common_base(batch.data)
-        if base is not None:
-            # all tensors are consecutive slices of one host buffer (torch.stack(...).unbind(0), the
-            # usual product of an evidence transform): one large copy instead of one per observed node
-            base = base if base.is_pinned() else base.pin_memory()
-            whole = base.to(self._device, ts.dtype, non_blocking=True)
-            moved._data, pos = [], 0
-            for d in batch.data:
-                moved._data.append(whole[pos : pos + d.numel()].view(d.shape))
-                pos += d.numel()
-            return moved
-        moved._data = [(d if d.is_pinned() or d.is_cuda else d.pin_memory()).to(self._device, ts.dtype, non_blocking=True)
-                       for d in batch.data]
+        moved._data = _to_device(batch.data, self._device, ts.dtype, non_blocking=True, pin=True)
         return moved
-
-    @staticmethod
-    def _common_base(tensors):
-        """The flat host tensor that ``tensors`` tile back to back, or None."""
-        first = tensors[0]
-        if first.is_cuda or not first.is_contiguous():
-            return None
-        storage_ptr = first.untyped_storage().data_ptr()
-        start, pos = first.storage_offset(), first.storage_offset()
-        for t in tensors:
-            if (t.is_cuda or t.dtype != first.dtype or not t.is_contiguous() or t.storage_offset() != pos
-                    or t.untyped_storage().data_ptr() != storage_ptr):
-                return None
-            pos += t.numel()
-        if len(tensors) < 2:
-            return None
-        flat = torch.empty(0, dtype=first.dtype).set_(first.untyped_storage(), start, (pos - start,))
-        return flat
 
     def __iter__(self):
         if self._device.type != "cuda":
