@@ -654,6 +654,25 @@ int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stre
       bn::launch(bn::evidence_scatter_pairs<double>, dim3((uint32_t)((p.npad + 511) / 512), cnt), dim3(256), 0, s,
                  static_cast<double*>(p.arena), (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,
                  p.N, p.tile, p.npad);
+    } else if ((size_t)64 * (max_states + 1) * p.elem_size <= 64 * 1024) {
+      // both sides coalesced through an LDS transpose
+      const size_t lds = (size_t)64 * (max_states + 1) * p.elem_size;
+      const dim3 grid((uint32_t)(p.npad / 64), cnt);
+      if (p.dtype == BN_F32) {
+        if (lds > 48 * 1024)
+          BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::evidence_scatter_lds<float>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        bn::launch(bn::evidence_scatter_lds<float>, grid, dim3(256), lds, s, static_cast<float*>(p.arena),
+                   (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first, p.d_obs_states + first, p.N,
+                   p.tile);
+      } else {
+        if (lds > 48 * 1024)
+          BN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn::evidence_scatter_lds<double>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        bn::launch(bn::evidence_scatter_lds<double>, grid, dim3(256), lds, s, static_cast<double*>(p.arena),
+                   (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first, p.d_obs_states + first, p.N,
+                   p.tile);
+      }
     } else if (p.dtype == BN_F32) {
       bn::launch(bn::evidence_scatter<float>, dim3(gx, cnt), dim3(256), 0, s, static_cast<float*>(p.arena),
                          (const void* const*)(p.d_evidence_ptrs + first), p.d_obs_off + first,

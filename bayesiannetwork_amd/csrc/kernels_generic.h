@@ -269,6 +269,37 @@ __global__ void __launch_bounds__(256) evidence_scatter(T* __restrict__ arena,
   arena[obs_off[o] + idx] = n < N ? src[n * S + s] : (T)1;
 }
 
+// The same copy with both sides coalesced: a block takes 64 observations of one observed node,
+// reads their S * 64 consecutive source elements into LDS and writes them out row by row
+// (the element-per-thread version above reads with a stride of S elements).
+//   grid = (npad / 64, num_observed), block = 256, dynamic LDS = 64 * (max S + 1) * sizeof(T)
+template <typename T>
+__global__ void __launch_bounds__(256) evidence_scatter_lds(T* __restrict__ arena,
+                                                           const void* const* __restrict__ sources,
+                                                           const int64_t* __restrict__ obs_off,
+                                                           const int32_t* __restrict__ obs_states, int64_t N,
+                                                           int32_t tile) {
+  extern __shared__ __align__(16) unsigned char scatter_lds[];
+  T* stage = reinterpret_cast<T*>(scatter_lds);  // [64][S + 1]
+  const int32_t o = blockIdx.y;
+  const int32_t S = obs_states[o];
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const T* src = static_cast<const T*>(sources[o]);
+  const int32_t count = 64 * S;
+  for (int32_t idx = threadIdx.x; idx < count; idx += 256) {
+    const int32_t l = idx / S, st = idx - l * S;
+    stage[l * (S + 1) + st] = n0 + l < N ? src[n0 * S + idx] : (T)1;
+  }
+  __syncthreads();
+  const int64_t t = n0 / tile;
+  const int32_t lt0 = (int32_t)(n0 % tile);
+  T* dst = arena + obs_off[o] + t * S * (int64_t)tile + lt0;
+  for (int32_t idx = threadIdx.x; idx < count; idx += 256) {
+    const int32_t st = idx >> 6, l = idx & 63;
+    dst[(int64_t)st * tile + l] = stage[l * (S + 1) + st];
+  }
+}
+
 // Writes a batch of addresses, handed over as kernel arguments, into a device table.  Kernel
 // arguments are captured at launch, so the caller's table needs no staging buffer and the upload is
 // ordered with the stream without any host-side wait.
