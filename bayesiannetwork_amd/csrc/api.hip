@@ -92,6 +92,8 @@ std::vector<ProfRecord> g_prof;
 std::atomic<bool> g_profiling{false};
 bool g_region_open = false;
 std::string g_prof_prefix;  // only labels starting with this are timed
+int32_t g_prof_stride = 1;  // of the regions that qualify, every g_prof_stride-th is timed
+int64_t g_prof_seen = 0;
 
 std::vector<hipEvent_t> g_event_pool;  // events are recycled: creating one costs far more than using it
 
@@ -121,6 +123,7 @@ void prof_begin(const std::string& label, double alg_bytes, hipStream_t) {
   if (!g_profiling.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (!g_prof_prefix.empty() && label.compare(0, g_prof_prefix.size(), g_prof_prefix) != 0) return;
+  if (g_prof_seen++ % g_prof_stride != 0) return;
   ProfRecord r;
   r.label = label;
   r.alg_bytes = alg_bytes;
@@ -963,6 +966,14 @@ int bn_profile_enable(int32_t enabled) {
 int bn_profile_only(const char* label_prefix) {
   std::lock_guard<std::mutex> lock(g_prof_mutex);
   g_prof_prefix = label_prefix ? label_prefix : "";
+  return BN_OK;
+}
+
+int bn_profile_stride(int32_t every) {
+  if (every < 1) return fail(BN_ERR_INVALID, "stride must be at least 1");
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof_stride = every;
+  g_prof_seen = 0;
   return BN_OK;
 }
 

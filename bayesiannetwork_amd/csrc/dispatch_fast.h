@@ -390,6 +390,9 @@ inline int prepare_fast(Plan& p) {
     // small batches cannot fill the chip anyway; there the combine sets the limit: its waves
     // each walk a share of the chunks, three groups of four at most
     want = std::min<int64_t>(want, 4 * kCombineMaxWaves * 3);
+    // in between (a few thousand observations) the combine, which reads every chunk's partial
+    // product, costs as much as the leaf-family launch itself: 32 chunks measured best at 7 500
+    if (p.ntiles >= 16) want = std::min<int64_t>(want, 32);
     if (env_wide_chunks() > 0) want = env_wide_chunks();
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
     // the leaf-family kernel keeps a chunk's exponents in 16 bits

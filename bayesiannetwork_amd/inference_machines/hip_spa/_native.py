@@ -91,6 +91,8 @@ def _declare(lib):
     lib.bn_profile_enable.argtypes = [c_int32]
     lib.bn_profile_only.restype = c_int
     lib.bn_profile_only.argtypes = [c_char_p]
+    lib.bn_profile_stride.restype = c_int
+    lib.bn_profile_stride.argtypes = [c_int32]
     lib.bn_profile_report.restype = c_int
     lib.bn_profile_report.argtypes = [c_char_p, c_int64]
 
@@ -102,7 +104,7 @@ EXPORTS = (
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_from", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
     "bn_exact_log_likelihood", "bn_exact_marginal",
-    "bn_profile_enable", "bn_profile_report", "bn_profile_only",
+    "bn_profile_enable", "bn_profile_report", "bn_profile_only", "bn_profile_stride",
 )
 
 

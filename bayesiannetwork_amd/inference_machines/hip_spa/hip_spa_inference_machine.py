@@ -82,11 +82,13 @@ class _FactorGraphView:
         return self._G
 
 
-def enable_profiling(enabled: bool = True, only: Optional[str] = None) -> None:
+def enable_profiling(enabled: bool = True, only: Optional[str] = None, stride: int = 1) -> None:
     """Process-wide: time every kernel launch with HIP events attached to its dispatch (benchmark
-    use); ``only`` restricts the timing to kernels whose report label starts with it."""
+    use); ``only`` restricts the timing to kernels whose report label starts with it, ``stride`` to
+    every stride-th of those launches."""
     lib = _native.load()
     _native.check(lib.bn_profile_only(only.encode() if only else None))
+    _native.check(lib.bn_profile_stride(int(stride)))
     _native.check(lib.bn_profile_enable(1 if enabled else 0))
 
 

@@ -301,6 +301,13 @@ int bn_profile_report(char* buffer, int64_t capacity);
  * benchmark that wants one kernel's durations from inside its timed region limits the timing to it.
  */
 int bn_profile_only(const char* label_prefix);
+/*
+ * Of the launches that qualify, time only every `every`-th (1 = all of them).  A timed dispatch is
+ * fenced off from its neighbours, so timing every launch of a kernel inside a benchmark's timed
+ * region slows the region down by a few per cent; a stride that is coprime to the number of such
+ * launches per step still samples every kind of launch evenly.
+ */
+int bn_profile_stride(int32_t every);
 
 #ifdef __cplusplus
 }
