@@ -21,7 +21,13 @@ $(OBJ)/%.o: $(SRC)/%.cpp $(HDRS)
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c -o $@ $<
 
-clean:
-	rm -rf $(OUT) $(OBJ)
+# plain C++ against the C ABI (no Python, no torch): examples/c_abi_demo
+demo: examples/c_abi_demo
 
-.PHONY: all clean
+examples/c_abi_demo: examples/c_abi_demo.cpp $(OUT) include/bn_hip.h
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< -L$(dir $(OUT)) -lbn_hip -Wl,-rpath,'$$ORIGIN/../$(dir $(OUT))'
+
+clean:
+	rm -rf $(OUT) $(OBJ) examples/c_abi_demo
+
+.PHONY: all clean demo

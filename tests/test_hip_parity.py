@@ -274,3 +274,23 @@ def test_products_that_leave_the_floating_point_range(num_children, dtype, tiny)
         assert not got.isnan().any() and not fam.isnan().any(), nodes[j].name
         np.testing.assert_allclose(got.cpu().double().numpy(), oracle.infer_single(j).double().numpy(), rtol=tol, atol=1e-12)
         np.testing.assert_allclose(fam.cpu().double().numpy(), oracle.infer_family(j).double().numpy(), rtol=tol, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_c_abi_from_plain_cpp():
+    """examples/c_abi_demo (built by `make demo`): the docs-1 network through the C ABI from C++ with
+    hipMalloc'ed buffers, no Python or torch in the process.  It checks the documented posteriors
+    itself (docs/1. Simple Bayesian network.md:70-75) and exits non-zero on a mismatch; here its
+    printed log-likelihood is compared with the reference's fixture as well."""
+    import os
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/c_abi_demo has not been built (make demo)")
+    done = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "P(Q | Y=0) = [0.117647058824, 0.882352941176]" in done.stdout
+    ll = float(re.search(r"log-likelihood \(sum\) = (-?[0-9.]+)", done.stdout).group(1))
+    assert abs(ll - float(Fixture("c1_docs1_f64")["out/ll_sum"])) < 1e-9
