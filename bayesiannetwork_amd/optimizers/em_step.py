@@ -90,6 +90,10 @@ class FlatModel:
         every node; a second ``optimize`` call on the same network finds it ready)."""
         model = network.__dict__.get("_flat_model")
         if model is not None:
+            store = model._store
+            if (store is not None and store.complete and store.network is network
+                    and store.flat.device == model.device and store.flat.dtype == model.dtype):
+                return model  # every node still reads the shared buffer: nothing can have changed shape
             cpts = [n.cpt for n in network.nodes]
             if (model.shapes != [tuple(c.shape) for c in cpts] or cpts[0].device != model.device
                     or cpts[0].dtype != model.dtype):
