@@ -415,7 +415,8 @@ int upload_evidence_table(bn::Plan& p, const void* const* evidence_dev, hipStrea
 
 // For an ingesting first iteration: per fused family group, the evidence source of every leaf in
 // the group's own order (the leaf's all-ones stand-in array when it is not observed).
-int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStream_t s) {
+int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStream_t s,
+                          const uint8_t* states_dev = nullptr) {
   bn::FastState* st = bn::fast_state(p);
   for (auto& kv : st->fused) {
     bn::FusedFamily& fam = kv.second;
@@ -423,7 +424,12 @@ int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStrea
     if (fam.wide_index2 >= 0 || g.dims[1] != 2) continue;
     const char* ones = static_cast<const char*>(p.arena) + (size_t)p.ones_off * p.elem_size;
     std::vector<const void*> src(g.nodes.size());
-    for (size_t k = 0; k < src.size(); ++k) src[k] = fam.ev_index[k] >= 0 ? evidence_dev[fam.ev_index[k]] : ones;
+    for (size_t k = 0; k < src.size(); ++k) {
+      if (states_dev)  // row of the leaf in the [num_observed][N] state matrix (all leaves observed)
+        src[k] = states_dev + (int64_t)fam.ev_index[k] * p.N;
+      else
+        src[k] = fam.ev_index[k] >= 0 ? evidence_dev[fam.ev_index[k]] : ones;
+    }
     if (src == fam.src_on_device) continue;
     for (size_t first = 0; first < src.size(); first += bn::kAddressBatch) {
       const int32_t cnt = (int32_t)std::min<size_t>(src.size() - first, bn::kAddressBatch);
@@ -931,6 +937,32 @@ int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_
   if (int rc = upload_family_sources(p, evidence_dev, s)) return rc;
   p.obs_pending = false;  // the first factor pass writes every observation array
   bn::set_ingest_next(p, true);
+  const int rc = bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
+  bn::set_ingest_next(p, false);
+  return rc;
+}
+
+int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
+                                 int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
+                                 void* stream) {
+  if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
+  bn::Plan& p = plan->p;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // as bn_em_statistics_from; a lane reads its two observations as one 16-bit load, so N must be
+  // even and the matrix 2-byte aligned, and every leaf of the ingesting groups must be observed
+  const bool ingest = !p.observed.empty() && states_dev && p.fresh && num_iterations >= 2 && p.N >= 2 &&
+                      p.N % 2 == 0 && reinterpret_cast<uintptr_t>(states_dev) % 2 == 0 &&
+                      bn::ingest_states_possible(p);
+  if (!ingest) {
+    if (int rc = bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)) return rc;
+    return bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
+  }
+  if (int rc = complete_pending(p, s)) return rc;
+  if (int rc = upload_family_sources(p, nullptr, s, states_dev)) return rc;
+  p.obs_pending = false;  // the first factor pass writes every observation array
+  bn::set_ingest_next(p, true, true, on_value, off_value);
   const int rc = bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
   bn::set_ingest_next(p, false);
   return rc;

@@ -90,6 +90,9 @@ struct FastState {
   // after a reset can read the evidence from the caller's arrays and write the arena copy itself.
   bool ingest_ok = false;
   bool ingest_next = false;  // the coming first iteration does so (evidence pointers are on the device)
+  bool ingest_states = false;  // ... from uint8 states (bn_enter_evidence_states' format) instead of float arrays
+  bool ingest_all_observed = false;  // every leaf of every ingesting group is observed (the uint8 route needs it)
+  double ingest_on = 1.0, ingest_off = 0.0;
 };
 
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
@@ -181,8 +184,18 @@ inline bool ingest_possible(const Plan& p) {
   return st && st->ingest_ok;
 }
 
-inline void set_ingest_next(Plan& p, bool on) {
-  if (FastState* st = fast_state(p)) st->ingest_next = on;
+inline void set_ingest_next(Plan& p, bool on, bool from_states = false, double on_value = 1.0, double off_value = 0.0) {
+  if (FastState* st = fast_state(p)) {
+    st->ingest_next = on;
+    st->ingest_states = on && from_states;
+    st->ingest_on = on_value;
+    st->ingest_off = off_value;
+  }
+}
+
+inline bool ingest_states_possible(const Plan& p) {
+  FastState* st = fast_state(p);
+  return st && st->ingest_ok && st->ingest_all_observed;
 }
 
 inline void cpts_changed_fast(Plan& p) {
@@ -352,6 +365,10 @@ inline int prepare_fast(Plan& p) {
         for (int32_t j : p.fgroups[kv.first].nodes) ingestible[j] = 1;
     st.ingest_ok = kLeafVec == 2 && !p.observed.empty();
     for (int32_t o : p.observed) st.ingest_ok = st.ingest_ok && ingestible[o];
+    st.ingest_all_observed = st.ingest_ok;
+    for (const auto& kv : st.fused)
+      if (kv.second.wide_index2 < 0 && p.fgroups[kv.first].dims[1] == 2)
+        for (int32_t e : kv.second.ev_index) st.ingest_all_observed = st.ingest_all_observed && e >= 0;
   }
   {
     std::vector<int64_t> offs;
@@ -688,11 +705,15 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
                               const T* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
                               bool with_counts = true) {
   int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
-  if (fresh && mode == kLeafLoop && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next) state = kLeafIngest;
+  if (fresh && mode == kLeafLoop && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next)
+    state = fast_state(p)->ingest_states ? kLeafIngestStates : kLeafIngest;
   LeafFamilyFn<T> fn = nullptr;
   switch (mode + 3 * state) {
     case kLeafLoop + 3 * kLeafIngest:
       fn = leaf_family_lookup_pairs<T, kLeafLoop + 3 * kLeafIngest>(g.dims[0]);
+      break;
+    case kLeafLoop + 3 * kLeafIngestStates:
+      fn = leaf_family_lookup_pairs<T, kLeafLoop + 3 * kLeafIngestStates>(g.dims[0]);
       break;
 #define X(M)                                                                                                    \
   case M:                                                                                                       \
@@ -751,6 +772,8 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.scaled2 = w2 ? w2->scaled : nullptr;
   a.m_state = static_cast<T*>(fam.m_state);
   a.src = fam.d_src;
+  a.on_value = (T)fast_state(p)->ingest_on;
+  a.off_value = (T)fast_state(p)->ingest_off;
   int64_t waves = (int64_t)fam.chunks * p.ntiles * leaf_parts(p);
   if (wide4) {
     const int32_t K = (int32_t)g.nodes.size();

@@ -38,6 +38,7 @@ struct LeafFamilyArgs {
   // kLeafIngest only: per family, the caller's evidence array ([N][2], row-major) of its leaf, or
   // the leaf's stand-in observation array in the arena (all ones) when it is not observed
   const void* const* src;
+  T on_value, off_value;  // kLeafIngestStates: what an observed / any other state's row receives
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
@@ -56,7 +57,9 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 //   kLeafIngest      as kLeafFresh, and the observations have not been copied into the arena yet:
 //                    they are read from the caller's arrays and the arena copy is written on the
 //                    way (two-state leaves, two observations per lane, kLeafLoop only).
-constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafIngest = 3;
+//   kLeafIngestStates  as kLeafIngest, from compact hard evidence: one uint8 state per observation
+//                    (bn_enter_evidence_states' format); the arena copy holds on_value / off_value.
+constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafIngest = 3, kLeafIngestStates = 4;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -164,7 +167,7 @@ struct LeafState {
   fv<T, V> z;  // the leaf's normaliser for this iteration: sum_s ev[s] * (previous message from the factor)[s]
 };
 
-template <typename T, bool INGEST = false>
+template <typename T, int INGEST = 0>
 __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T* __restrict__ cpts,
                                                  const LeafFamilyArgs<T>& a, int32_t k) {
   LeafPtrs<T> p;
@@ -177,7 +180,7 @@ __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T*
   p.obs = arena + a.obs_off[k];
   p.cpt = cpts + a.cpt_off[k];
   p.src = nullptr;
-  if constexpr (INGEST) p.src = static_cast<const T*>(a.src[k]);
+  if constexpr (INGEST != 0) p.src = static_cast<const T*>(a.src[k]);
   return p;
 }
 
@@ -197,11 +200,26 @@ __device__ __forceinline__ fv<T, V> recipv(const fv<T, V>& x) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, splat<T, V>(1.f)), r, r);
 }
 
-template <typename T, int S, int V, int STATE, bool INGEST = false>
+template <typename T, int S, int V, int STATE, int INGEST = 0>
 __device__ __forceinline__ LeafState<T, S, V> leaf_state(const LeafPtrs<T>& p, const LeafFamilyArgs<T>& a, int64_t t,
                                                       int32_t col) {
   LeafState<T, S, V> st;
-  if constexpr (INGEST && S == 2 && V == 2) {
+  if constexpr (INGEST == 2 && S == 2 && V == 2) {
+    // compact hard evidence: this lane's two observations are two consecutive bytes (N is even,
+    // so a lane's pair never straddles the end except as a whole)
+    const int64_t n0 = t * tile_of<T>::value + col;
+    const bool tail = n0 + 1 >= a.N;
+    const int64_t at = tail ? a.N - 2 : n0;
+    const uint32_t pair = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(p.src) + at);
+    const uint32_t s0 = pair & 0xffu, s1 = pair >> 8;
+    st.ev[0][0] = s0 == 0 ? a.on_value : a.off_value;
+    st.ev[1][0] = s0 == 1 ? a.on_value : a.off_value;
+    st.ev[0][1] = s1 == 0 ? a.on_value : a.off_value;
+    st.ev[1][1] = s1 == 1 ? a.on_value : a.off_value;
+    T* dst = const_cast<T*>(p.obs);
+    storev<T, V>(dst, t * S, col, st.ev[0]);
+    storev<T, V>(dst, t * S + 1, col, st.ev[1]);
+  } else if constexpr (INGEST == 1 && S == 2 && V == 2) {
     // This lane's two observations are four consecutive elements of the caller's [N][2] array
     // (an unobserved leaf reads the all-ones array instead).  Branch-free: a lane whose second
     // observation lies beyond N loads the array's last four elements and takes the last pair as
@@ -247,8 +265,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
                                                      LeafFamilyArgs<T> a) {
   constexpr bool FULL = MODE % 3 == kLeafFull;
   constexpr bool REDUCE = MODE % 3 == kLeafReduce;
-  constexpr bool INGEST = MODE / 3 == kLeafIngest;
-  constexpr int32_t STATE = INGEST ? kLeafFresh : MODE / 3;
+  constexpr int32_t INGEST = MODE / 3 == kLeafIngest ? 1 : (MODE / 3 == kLeafIngestStates ? 2 : 0);
+  constexpr int32_t STATE = INGEST != 0 ? kLeafFresh : MODE / 3;
   constexpr int32_t kParts = tile_of<T>::value / (64 * V);
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;

@@ -300,6 +300,17 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def _enter_hard_evidence(self, evidence: HardEvidence) -> None:
         """State indices go to the engine as they are (one byte per observed node and observation);
         the observation slots end up holding exactly ``evidence.data``."""
+        states = self._hard_states(evidence)
+        with torch.cuda.device(self._device):
+            _native.check(
+                self._lib.bn_enter_evidence_states(self._plan, ctypes.c_void_p(states.data_ptr()),
+                                                   evidence.on_value, evidence.off_value, self._stream())
+            )
+        self._evidence_keepalive = states
+        self.must_iterate = True
+
+    def _hard_states(self, evidence: HardEvidence) -> torch.Tensor:
+        """The evidence's state matrix on this machine's device, checked against the observed nodes."""
         states = evidence.states
         if states.device != self._device:
             states = states.to(self._device)
@@ -308,13 +319,9 @@ class HipSpaInferenceMachine(IInferenceMachine):
                                f"{(len(self.observed_nodes), self._n)}")
         if evidence.num_states != [int(node.num_states) for node in self.observed_nodes]:
             raise RuntimeError("hard evidence was built for other state counts than the observed nodes have")
-        with torch.cuda.device(self._device):
-            _native.check(
-                self._lib.bn_enter_evidence_states(self._plan, ctypes.c_void_p(states.data_ptr()),
-                                                   evidence.on_value, evidence.off_value, self._stream())
-            )
-        self._evidence_keepalive = states
-        self.must_iterate = True
+        if not states.is_contiguous():
+            states = states.contiguous()
+        return states
 
     def _iterate(self) -> None:
         callback = self._settings.callback
@@ -427,7 +434,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
         the engine then gets both in one call and may read the evidence while it runs the first
         iteration instead of copying it first (same results, same state afterwards)."""
         plain = self._settings.callback is None and self._settings.convergence_tolerance is None
-        if evidence is not None and (isinstance(evidence, HardEvidence) or not plain):
+        if evidence is not None and not plain:
             self.enter_evidence(evidence)
             evidence = None
         if evidence is None and (not self.must_iterate or not plain):
@@ -436,7 +443,16 @@ class HipSpaInferenceMachine(IInferenceMachine):
         counts = torch.empty((self._lib.bn_plan_cpt_elements(self._plan),), device=self._device, dtype=torch.float64)
         average = 1 if self._settings.average_log_likelihood else 0
         with torch.cuda.device(self._device):
-            if evidence is not None:
+            if isinstance(evidence, HardEvidence):
+                states = self._hard_states(evidence)
+                _native.check(
+                    self._lib.bn_em_statistics_from_states(
+                        self._plan, ctypes.c_void_p(states.data_ptr()), evidence.on_value, evidence.off_value,
+                        self._num_iterations, average, ctypes.c_void_p(ll.data_ptr()),
+                        ctypes.c_void_p(counts.data_ptr()), self._stream())
+                )
+                self._evidence_keepalive = states
+            elif evidence is not None:
                 cached = self._evidence_table(evidence)
                 _native.check(
                     self._lib.bn_em_statistics_from(self._plan, cached[2], self._num_iterations, average,

@@ -179,9 +179,11 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="observations per GPU per step")
     ap.add_argument("--model", choices=["c3a", "c3b", "c5"], default="c3a")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
-    ap.add_argument("--evidence", choices=["resident", "host-float", "host-uint8"], default="resident",
-                    help="resident: batches already in HBM (the contract's figure).  host-*: batches start in host "
-                         "memory every step and cross PCIe through PrefetchingLoader (PCIe-inclusive rate)")
+    ap.add_argument("--evidence", choices=["resident", "resident-uint8", "host-float", "host-uint8"],
+                    default="resident",
+                    help="resident: batches already in HBM as the reference's float tensors (the contract's figure).  "
+                         "resident-uint8: in HBM as uint8 state indices (HardEvidence).  host-*: batches start in "
+                         "host memory every step and cross PCIe through PrefetchingLoader (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -223,7 +225,12 @@ def main():
     logger = OptimizerLogger()
 
     host_batches = None
-    if args.evidence != "resident":
+    if args.evidence == "resident-uint8":
+        from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
+        batches = [HardEvidence(torch.stack([d.argmax(dim=1) for d in b.data]).to(torch.uint8),
+                                [d.shape[1] for d in b.data], ts, on_value=float(b.data[0].max()),
+                                off_value=float(b.data[0].min())) for b in batches]
+    elif args.evidence != "resident":
         from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence, PrefetchingLoader
         host_ts = TorchSettings(device="cpu", dtype=args.dtype)
         host_batches = []

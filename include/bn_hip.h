@@ -193,6 +193,16 @@ int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_
                           double* ll_out_dev, double* accum_dev, void* stream);
 
 /*
+ * The same for compact hard evidence: bn_enter_evidence_states followed by bn_em_statistics, as
+ * one call (arguments of both).  The first iteration reads the state bytes itself and writes the
+ * observation slots on the way when, in addition to the conditions above, num_observations is
+ * even and every leaf of the fused groups is observed; otherwise it is literally the two calls.
+ */
+int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
+                                 int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
+                                 void* stream);
+
+/*
  * M-step for the whole network in one launch.  For every CPT row (last axis) of every node:
  *   target = count_sums_row / sum(count_sums_row)
  *   target = (1 - regularization) * target + regularization / num_states      if regularization != 0

@@ -253,6 +253,39 @@ def test_em_statistics_with_evidence_on_networks_without_the_fused_path():
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n", [24, 77, 300, 1026])
+def test_em_statistics_with_hard_evidence_equals_the_two_call_route(dtype, n):
+    """bn_em_statistics_from_states = bn_enter_evidence_states + bn_em_statistics.  With an even N the
+    first iteration of the 784-leaf model reads the state bytes itself; N = 77 must take the two-call
+    route inside the engine.  Results bit-identical either way, the observation slots afterwards hold
+    exactly the tensors the hard evidence stands for."""
+    from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture("c3a_784_f64" if dtype == "float64" else "c3a_784_f32")
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    network, observed, by_name = fx.build(ts)
+    gen = torch.Generator().manual_seed(n)
+    states = (torch.rand((len(observed), n), generator=gen) < 0.2).to(torch.uint8).to("cuda")
+    ev = HardEvidence(states, [2] * len(observed), ts, on_value=0.9999995, off_value=5e-7)
+    settings = SpaInferenceMachineSettings(ts, False)
+
+    two_calls = HipSpaInferenceMachine(settings, network, observed, n)
+    two_calls.enter_evidence(ev)
+    ll_a, counts_a = two_calls.em_statistics()
+    one_call = HipSpaInferenceMachine(settings, network, observed, n)
+    ll_b, counts_b = one_call.em_statistics(ev)
+    assert ll_a.item() == ll_b.item()
+    assert torch.equal(counts_a, counts_b)
+    for node, want in list(zip(observed, ev.data))[::131]:
+        assert torch.equal(one_call.observation(node), want), node.name
+    probe = [by_name["Q"], observed[0], observed[-1]]
+    for a, b in zip(one_call.infer_single_nodes(probe), two_calls.infer_single_nodes(probe)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("lr,reg", [(None, None), (0.1, 0.01), (0.3, None), (None, 0.05)])
 def test_m_step_kernel_equals_the_tensor_formulas(dtype, lr, reg):
     """bn_m_step against the same M-step written with torch tensor operations (FlatModel.m_step,
