@@ -837,13 +837,17 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
   if (!st || st->fused.empty()) return 0;
   for (auto& kv : st->fused)
     if (!kv.second.pending) return 0;
+  // every family gets an equal share of the partial-sum slots (the kernel is grid-stride, so a
+  // launch with fewer blocks than rows is still complete)
+  const int32_t share = max_blocks / (int32_t)st->fused.size();
+  if (share < 1) return -1;
   int32_t used = 0;
   bool listed_done = false;
   for (auto& kv : st->fused) {
     const FusedFamily& fam = kv.second;
     const int64_t n_listed = listed_done ? 0 : st->n_ll_offs;
     const int64_t rows = n_listed + fam.ll_rows;
-    const int32_t blocks = (int32_t)std::min<int64_t>(max_blocks - used, rows * ((p.npad + 255) / 256));
+    const int32_t blocks = (int32_t)std::min<int64_t>(share, rows * ((p.npad + 255) / 256));
     if (blocks <= 0) return -1;
     if (p.dtype == 0) {
       launch(ll_partial_listed<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(p.arena),

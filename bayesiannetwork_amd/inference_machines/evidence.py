@@ -100,6 +100,13 @@ class HardEvidence(Evidence):
             raise ValueError("states must be [num_observed_nodes, num_observations] with one num_states entry per row")
         if max(num_states) > 256:
             raise ValueError("state indices are stored in 8 bits")
+        if states.numel() and not states.dtype.is_floating_point:
+            # before the 8-bit cast: a wrapped value would silently become another valid state
+            limits = torch.tensor([int(s) for s in num_states], device=states.device).unsqueeze(1)
+            if bool(((states < 0) | (states >= limits)).any()):
+                raise ValueError("every state index must satisfy 0 <= state < num_states of its row")
+        elif states.numel():
+            raise ValueError("states must be an integer tensor")
         self.torch_settings = torch_settings
         self.num_observed_nodes = int(states.shape[0])
         self.num_observations = int(states.shape[1])
@@ -160,6 +167,38 @@ class PrefetchingLoader:
         moved._data = _to_device(batch.data, self._device, ts.dtype, non_blocking=True, pin=True)
         return moved
 
+    @staticmethod
+    def _device_tensors(moved):
+        """The device tensors a moved batch owns, one per storage."""
+        if isinstance(moved, HardEvidence):
+            tensors = [moved.states]
+        elif isinstance(moved, Evidence):
+            tensors = list(moved._data)
+        elif isinstance(moved, torch.Tensor):
+            tensors = [moved]
+        elif isinstance(moved, (list, tuple)):
+            tensors = [t for t in moved if isinstance(t, torch.Tensor)]
+        else:
+            tensors = []
+        seen, out = set(), []
+        for t in tensors:
+            key = t.untyped_storage().data_ptr()
+            if t.is_cuda and key not in seen:
+                seen.add(key)
+                out.append(t)
+        return out
+
+    def _hand_over(self, pending):
+        """Make the consumer's stream wait for the copy, and tell the caching allocator that the
+        batch is used on that stream: its memory was allocated on the copy stream, and without this
+        a later copy could reuse it while the consumer's kernels are still queued."""
+        moved, ready = pending
+        consumer = torch.cuda.current_stream(self._device)
+        consumer.wait_event(ready)
+        for t in self._device_tensors(moved):
+            t.record_stream(consumer)
+        return moved
+
     def __iter__(self):
         if self._device.type != "cuda":
             yield from self._batches
@@ -172,12 +211,10 @@ class PrefetchingLoader:
                 ready = torch.cuda.Event()
                 ready.record(copy_stream)
             if pending is not None:
-                torch.cuda.current_stream(self._device).wait_event(pending[1])
-                yield pending[0]
+                yield self._hand_over(pending)
             pending = (moved, ready)
         if pending is not None:
-            torch.cuda.current_stream(self._device).wait_event(pending[1])
-            yield pending[0]
+            yield self._hand_over(pending)
 
 
 class EvidenceLoader:

@@ -359,9 +359,12 @@ def test_hard_evidence_fills_the_observation_slots_like_its_tensors(dtype, n):
         compact.enter_evidence(hard[0:2] if n > 2 else HardEvidence(states[:, :1].repeat(1, n + 1), hard.num_states, ts))
 
 
-def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory():
+@pytest.mark.parametrize("deferred", [False, True])
+def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory(deferred):
     """Host-resident uint8 batches through PrefetchingLoader give the same EM trajectory as the same
-    evidence resident on the device as float tensors."""
+    evidence resident on the device as float tensors.  With deferred logging no step waits for the
+    host, so a device batch is dropped while the kernels that read it may still be queued: the
+    loader has to keep its memory from being reused by a later copy until they have run."""
     import copy
     from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
     from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence, PrefetchingLoader
@@ -371,7 +374,7 @@ def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory():
 
     ts = TorchSettings(device="cuda", dtype="float32")
     host = TorchSettings(device="cpu", dtype="float32")
-    n, batches = 200, 4
+    n, batches = (20000, 12) if deferred else (200, 4)
 
     def build():
         torch.manual_seed(2)
@@ -388,7 +391,8 @@ def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory():
         logger = OptimizerLogger()
         opt = EmBatchOptimizer(
             net, lambda network: HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), network, kids, n),
-            EmBatchOptimizerSettings(learning_rate=0.2, num_epochs=2, regularization=0.01), logger)
+            EmBatchOptimizerSettings(learning_rate=0.2, num_epochs=2, regularization=0.01,
+                                     deferred_logging=deferred), logger)
         if mode == "prefetched":
             loader = PrefetchingLoader(host_batches, "cuda")
         else:

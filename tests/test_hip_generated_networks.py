@@ -166,3 +166,53 @@ def test_generated_network_matches_oracle(name, dtype, n):
         want = oracle.infer_family(j).sum(dim=0)
         check(got, want, f"counts {node.name}")
         check(got2, want, f"counts via statistics {node.name}")
+
+
+@pytest.mark.parametrize("n", [10_000, 60_000])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents"])
+def test_several_fused_groups_at_large_batches(name, dtype, n):
+    """Plans with more than one fused leaf-family group share the partial-sum slots of the
+    log-likelihood reduction; at these batch sizes one group alone could fill all of them.  The
+    one-call statistics route must agree with iterate + log_likelihood + accumulate and with the
+    float64 oracle."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from oracle.spa_oracle import SpaOracle
+
+    spec, observed_names, iterations, loops, cpts, evidence, make = _build(name, dtype, n)
+    ts, network, by_name = make("cuda", dtype)
+    observed = [by_name[o] for o in observed_names]
+    ev_dev = [evidence[o].to(ts.dtype) for o in observed_names]
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations, allow_loops=loops)
+
+    one_call = HipSpaInferenceMachine(settings, network, observed, n)
+    one_call.enter_evidence(Evidence([e.to("cuda") for e in ev_dev], ts))
+    ll_a, counts_a = one_call.em_statistics()
+    # a later query re-reads the normalisers as stored in the plan dtype
+    assert abs(one_call.log_likelihood() - ll_a.item()) <= (1e-6 if dtype == "float32" else 1e-12) * abs(ll_a.item())
+
+    separate = HipSpaInferenceMachine(settings, network, observed, n)
+    separate.enter_evidence(Evidence([e.to("cuda") for e in ev_dev], ts))
+    separate.infer_single_nodes([observed[0]])  # bn_iterate
+    ll_b = separate.log_likelihood_tensor()     # bn_log_likelihood
+    counts_b = separate.expected_count_sums()   # bn_em_accumulate
+
+    f32 = dtype == "float32"
+    ll_rtol = 1e-6 if f32 else 1e-12
+    assert abs(ll_a.item() - ll_b.item()) <= ll_rtol * abs(ll_b.item())
+    np.testing.assert_allclose(counts_a.cpu().numpy(), counts_b.cpu().numpy(), rtol=2e-5 if f32 else 1e-10,
+                               atol=(1e-7 if f32 else 1e-12) * n)
+
+    ts64, network64, by_name64 = make("cpu", "float64")
+    for node, _, _ in spec:
+        by_name64[node].cpt = by_name[node].cpt.detach().cpu().double()
+    oracle = SpaOracle(network64, [by_name64[o] for o in observed_names], n, dtype=torch.float64,
+                       num_iterations=iterations, allow_loops=loops)
+    oracle.enter_evidence([e.double() for e in ev_dev])
+    want_ll = oracle.log_likelihood(False)
+    assert abs(ll_a.item() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
+    for j, got in enumerate(one_call.split_counts(counts_a)):
+        want = oracle.infer_family(j).sum(dim=0).numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5 if f32 else 1e-9,
+                                   atol=(1e-7 if f32 else 1e-11) * float(np.max(np.abs(want))))
