@@ -166,6 +166,44 @@ std::string flabel(const char* what, const bn::FactorGroup& g) {
 }
 constexpr int32_t kLlBlocks = 1024;
 
+// Reduction scratch of bn_em_statistics_static: partial sums of the log-likelihood and of the EM
+// counts live here instead of in memory the plan allocated.  One copy per GPU, held until the
+// process ends (8 MiB).  In host code the array's name is only a handle for
+// hipGetSymbolAddress; kernels and memsets get the per-device address from static_scratch().
+constexpr int64_t kStaticScratchElems = int64_t(1) << 20;
+static __device__ __align__(256) double scratch[kStaticScratchElems];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+double* g_static_scratch[kMaxDevices] = {};
+
+// Address of `scratch` on the current device (looked up once per device).
+int static_scratch(double** out) {
+  int device = 0;
+  hipError_t err = hipGetDevice(&device);
+  if (err != hipSuccess) return fail(BN_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(err));
+  if (device < 0 || device >= kMaxDevices) return fail(BN_ERR_INVALID, "device index beyond the static scratch table");
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (!g_static_scratch[device]) {
+    double* ptr = nullptr;
+    err = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (err != hipSuccess || !ptr)
+      return fail(BN_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(err));
+    g_static_scratch[device] = ptr;
+  }
+  *out = g_static_scratch[device];
+  return BN_OK;
+}
+
+// The plan's pointers are only valid on the device it was created on.
+int on_plan_device(const bn::Plan& p) {
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess || device != p.device)
+    return fail(BN_ERR_STATE, "the plan belongs to HIP device " + std::to_string(p.device) +
+                                  " but device " + std::to_string(device) + " is current");
+  return BN_OK;
+}
+
 void release(bn::Plan& p) {
   for (auto& g : p.vgroups) {
     if (g.d_in) (void)hipFree(g.d_in);
@@ -340,7 +378,10 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
   int64_t active_nodes = 0;
   for (auto& g : p.fgroups)
     if (!(use_reduced && bn::em_is_reduced(p, (size_t)(&g - p.fgroups.data())))) active_nodes += (int64_t)g.nodes.size();
-  const int32_t nchunks = active_nodes < p.n_nodes ? em_chunks(p, active_nodes) : em_chunks(p);
+  int32_t nchunks = active_nodes < p.n_nodes ? em_chunks(p, active_nodes) : em_chunks(p);
+  // never more chunks than the scratch in use has room for (the plan's own is sized for them)
+  if (p.cpt_total > 0)
+    nchunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nchunks, (p.scratch_elems - kLlBlocks) / p.cpt_total));
   double* partial = p.scratch + kLlBlocks;
   for (auto& g : p.fgroups) {
     const int32_t K = (int32_t)g.nodes.size();
@@ -502,6 +543,10 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
   } while (0)
 
   BN_TRY_HIP(hipGetDevice(&p.device));
+  {
+    double* unused = nullptr;
+    BN_TRY(static_scratch(&unused));  // set-up for bn_em_statistics_static, once per device
+  }
   p.device_bytes = 0;
   BN_TRY_HIP(hipMalloc(&p.arena, (size_t)p.arena_elems * p.elem_size));
   p.device_bytes += p.arena_elems * (int64_t)p.elem_size;
@@ -618,6 +663,7 @@ int64_t bn_plan_device_bytes(const bn_plan* plan) { return plan ? plan->p.device
 int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (int rc = complete_pending(p, static_cast<hipStream_t>(stream))) return rc;
   BN_HIP_CHECK(hipMemcpyAsync(p.cpts, cpts_dev, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice,
                               static_cast<hipStream_t>(stream)));
@@ -629,6 +675,7 @@ int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
 int bn_reset_messages(bn_plan* plan, void* stream) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
 }
@@ -636,6 +683,7 @@ int bn_reset_messages(bn_plan* plan, void* stream) {
 int bn_enter_evidence(bn_plan* plan, const void* const* evidence_dev, void* stream) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (p.observed.empty()) return BN_OK;
   if (!evidence_dev) return fail(BN_ERR_INVALID, "evidence_dev is null");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -702,6 +750,7 @@ int bn_enter_evidence_states(bn_plan* plan, const uint8_t* states_dev, double on
                              void* stream) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (p.observed.empty()) return BN_OK;
   if (!states_dev) return fail(BN_ERR_INVALID, "states_dev is null");
   if (p.tile % 4 != 0) return fail(BN_ERR_STATE, "observation tile is not a multiple of four");
@@ -736,6 +785,7 @@ int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   if (num_iterations < 0) return fail(BN_ERR_INVALID, "num_iterations must be >= 0");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = complete_pending(p, s)) return rc;
@@ -746,6 +796,7 @@ int bn_iterate(bn_plan* plan, int32_t num_iterations, void* stream) {
 int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_normalisers(p, s)) return rc;
@@ -770,6 +821,7 @@ int bn_log_likelihood(bn_plan* plan, int32_t average, double* out_dev, void* str
 int bn_normaliser_change(bn_plan* plan, double* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_normalisers(p, s)) return rc;
@@ -814,6 +866,7 @@ static int gather(bn::Plan& p, int64_t a_off, int64_t b_off, int32_t states, voi
 int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   if (int rc = complete_pending(p, static_cast<hipStream_t>(stream))) return rc;
   if (int rc = settle_normalisers(p, static_cast<hipStream_t>(stream))) return rc;
@@ -823,6 +876,7 @@ int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* s
 int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   const bn::EdgeLayout& e = p.edges[node];
   if (int rc = materialize(p, static_cast<hipStream_t>(stream))) return rc;
@@ -832,6 +886,7 @@ int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream)
 int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction, void* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (owner < 0 || owner >= p.n_nodes) return fail(BN_ERR_INVALID, "owner out of range");
   if (slot == -2) {
     if (p.observed_slot_of[owner] < 0) return fail(BN_ERR_INVALID, "node is not observed");
@@ -849,6 +904,7 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
 int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
   if (!plan || !out_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -875,6 +931,7 @@ int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream)
 int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream) {
   if (!plan || !accum_dev) return fail(BN_ERR_INVALID, "null argument");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = materialize(p, s)) return rc;
@@ -887,6 +944,7 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
   if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = complete_pending(p, s)) return rc;
@@ -914,11 +972,39 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
 }
 
+int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev,
+                            double* accum_dev, void* stream) {
+  if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
+  bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
+  const int64_t needed = kLlBlocks + (accum_dev ? p.cpt_total : 0);
+  if (needed > kStaticScratchElems)
+    return fail(BN_ERR_INVALID, "bn_em_statistics_static: the network's CPTs hold " + std::to_string(p.cpt_total) +
+                                    " entries; the static scratch has room for " +
+                                    std::to_string(kStaticScratchElems - kLlBlocks) + " (use bn_em_statistics)");
+  double* base = nullptr;
+  if (int rc = static_scratch(&base)) return rc;
+  // the same kernels as bn_em_statistics, with their partial sums in the static array
+  struct Swap {
+    bn::Plan& p;
+    double* own;
+    int64_t own_elems;
+    ~Swap() {
+      p.scratch = own;
+      p.scratch_elems = own_elems;
+    }
+  } swap{p, p.scratch, p.scratch_elems};
+  p.scratch = base;
+  p.scratch_elems = kStaticScratchElems;
+  return bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
+}
+
 int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_t num_iterations, int32_t average,
                           double* ll_out_dev, double* accum_dev, void* stream) {
   if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
   if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // The first iteration can take the evidence straight from the caller's arrays when nothing has
@@ -948,6 +1034,7 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
   if (!plan || !ll_out_dev) return fail(BN_ERR_INVALID, "null argument");
   if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // as bn_em_statistics_from; a lane reads its two observations as one 16-bit load, so N must be
@@ -974,6 +1061,7 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
   if (learning_rate >= 0.0 && !old_cpts_dev) return fail(BN_ERR_INVALID, "old_cpts_dev is null but a learning rate is given");
   if (regularization < 0.0 || regularization > 1.0) return fail(BN_ERR_INVALID, "regularization must be in [0, 1]");
   bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((uint32_t)((p.n_rows + 255) / 256));
   prof_begin("m_step", 0.0, s);

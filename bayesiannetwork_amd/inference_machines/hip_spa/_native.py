@@ -67,6 +67,8 @@ def _declare(lib):
     lib.bn_em_accumulate.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.bn_em_statistics.restype = c_int
     lib.bn_em_statistics.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.bn_em_statistics_static.restype = c_int
+    lib.bn_em_statistics_static.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.bn_em_statistics_from.restype = c_int
     lib.bn_em_statistics_from.argtypes = [c_void_p, POINTER(c_void_p), c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.bn_em_statistics_from_states.restype = c_int
@@ -104,7 +106,7 @@ EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
-    "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
+    "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_static", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
     "bn_exact_log_likelihood", "bn_exact_marginal",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only", "bn_profile_stride",

@@ -6,8 +6,9 @@
  * bn_last_error() then holds a message for the calling thread.  Device
  * pointers are ordinary HIP device addresses (e.g. tensor.data_ptr()); the
  * stream argument is a hipStream_t passed as void* (NULL = default stream).
- * A plan is bound to the HIP device it was created on, owns all message
- * buffers, and is not thread-safe; the caller keeps input/output buffers
+ * A plan is bound to the HIP device it was created on (calls made while another
+ * device is current fail with BN_ERR_STATE), owns all message buffers, and is
+ * not thread-safe; the caller keeps input/output buffers
  * alive until the stream has run the call.
  *
  * The reference package has no FFI layer: its seam is the Python ABC
@@ -177,6 +178,19 @@ int bn_em_accumulate(bn_plan* plan, double* accum_dev, void* stream);
  */
 int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
                      void* stream);
+
+/*
+ * bn_em_statistics for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): same arguments, same results, same state
+ * afterwards, and the call itself allocates and frees nothing.  No counterpart in the reference.
+ * The partial sums of its reductions (log-likelihood, expected counts) go to a static device array
+ * of 2^20 doubles (8 MiB per GPU, held until the process ends) instead of memory the plan owns;
+ * the message state still lives in the plan, which bn_plan_create allocated.  Fails with
+ * BN_ERR_INVALID when 1024 + bn_plan_cpt_elements(plan) exceeds the array.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (different streams or threads) race.
+ */
+int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev,
+                            double* accum_dev, void* stream);
 
 /*
  * bn_enter_evidence followed by bn_em_statistics, as one call: same arguments, same results, same

@@ -1,0 +1,134 @@
+"""bn_em_statistics_static (the entry point for callers that cannot allocate device memory) against
+bn_em_statistics, through the C ABI: two calls in a row on one GPU, the second on a smaller batch,
+so that the second call finds the first one's partial sums in the shared static scratch.
+
+Tolerance: the two entry points run the same kernels; only the number of chunks the expected-count
+partial sums are cut into may differ (it depends on the room in the scratch), which changes the
+order of a double-precision summation: 1e-12 relative on the log-likelihood, 1e-11 relative (+1e-13
+of the largest count) on the counts, for float32 and float64 plans alike.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _network(ts, leaves_a=40, leaves_b=20):
+    """Q(10) with fused (10,2) and (10,3) leaf families, plus a chain R(3) -> M(4) -> Z(5) on generic-sized
+    kernels; every fourth leaf unobserved."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+
+    gen = torch.Generator().manual_seed(11)
+
+    def cpt(shape):
+        p = torch.rand(shape, generator=gen, dtype=torch.float64) + 0.05
+        return (p / p.sum(-1, keepdim=True)).to(ts.dtype).to(ts.device)
+
+    q = Node(cpt((10,)), name="Q")
+    builder = BayesianNetworkBuilder().add_node(q)
+    observed = []
+    for i in range(leaves_a):
+        node = Node(cpt((10, 2)), name=f"A{i}")
+        builder.add_node(node, parents=q)
+        if i % 4:
+            observed.append(node)
+    for i in range(leaves_b):
+        node = Node(cpt((10, 3)), name=f"B{i}")
+        builder.add_node(node, parents=q)
+        if i % 4:
+            observed.append(node)
+    m = Node(cpt((10, 4)), name="M")
+    z = Node(cpt((4, 5)), name="Z")
+    builder.add_node(m, parents=q).add_node(z, parents=m)
+    observed.append(z)
+    return builder.build(), observed
+
+
+def _evidence(ts, observed, n, seed):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+
+    gen = torch.Generator().manual_seed(seed)
+    data = []
+    for node in observed:
+        soft = torch.rand((n, node.num_states), generator=gen, dtype=torch.float64) + 1e-3
+        data.append((soft / soft.sum(-1, keepdim=True)).to(ts.dtype).to(ts.device))
+    return Evidence(data, ts)
+
+
+def _statistics(entry, machine):
+    ll = torch.full((1,), float("nan"), device="cuda", dtype=torch.float64)
+    counts = torch.full((machine._lib.bn_plan_cpt_elements(machine._plan),), float("nan"), device="cuda",
+                        dtype=torch.float64)
+    rc = entry(machine._plan, machine.num_iterations, 0, ctypes.c_void_p(ll.data_ptr()),
+               ctypes.c_void_p(counts.data_ptr()), machine._stream())
+    assert rc == 0, machine._lib.bn_last_error().decode()
+    torch.cuda.synchronize()
+    return ll.item(), counts.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.inference_machines.hip_spa import _native
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    lib = _native.load()
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    network, observed = _network(ts)
+    settings = SpaInferenceMachineSettings(ts, False)
+
+    last = None
+    for n, seed in ((1000, 5), (300, 6)):  # the second call is the smaller one
+        evidence = _evidence(ts, observed, n, seed)
+        pair = []
+        for entry in (lib.bn_em_statistics_static, lib.bn_em_statistics):
+            machine = HipSpaInferenceMachine(settings, network, observed, n)
+            machine.enter_evidence(evidence)
+            pair.append((machine,) + _statistics(entry, machine))
+        (static_machine, ll_s, counts_s), (plain_machine, ll_p, counts_p) = pair
+        assert np.isfinite(ll_s) and np.isfinite(counts_s).all()
+        assert abs(ll_s - ll_p) <= 1e-12 * abs(ll_p)
+        np.testing.assert_allclose(counts_s, counts_p, rtol=1e-11, atol=1e-13 * float(np.abs(counts_p).max()))
+        # the state it leaves behind serves later queries like bn_em_statistics' does
+        for node in (observed[0], list(network.nodes)[0]):
+            a = static_machine.infer_single_nodes([node])[0]
+            b = plain_machine.infer_single_nodes([node])[0]
+            assert torch.equal(a, b)
+        last = static_machine
+
+    # a repeated call neither takes nor returns device memory
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    last.reset_messages()
+    _statistics(lib.bn_em_statistics_static, last)
+    assert torch.cuda.mem_get_info()[0] == free_before
+
+
+def test_static_scratch_entry_point_rejects_networks_beyond_its_scratch():
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.inference_machines.hip_spa import _native
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    lib = _native.load()
+    ts = TorchSettings(device="cuda", dtype="float32")
+    parents = [Node(torch.full((32,), 1 / 32, device="cuda"), name=f"P{i}") for i in range(3)]
+    child = Node(torch.full((32, 32, 32, 32), 1 / 32, device="cuda"), name="C")  # 2^20 CPT entries
+    builder = BayesianNetworkBuilder()
+    for parent in parents:
+        builder.add_node(parent)
+    network = builder.add_node(child, parents=parents).build()
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, [child], 2)
+    ll = torch.zeros((1,), device="cuda", dtype=torch.float64)
+    counts = torch.zeros((lib.bn_plan_cpt_elements(machine._plan),), device="cuda", dtype=torch.float64)
+    rc = lib.bn_em_statistics_static(machine._plan, 2, 0, ctypes.c_void_p(ll.data_ptr()),
+                                     ctypes.c_void_p(counts.data_ptr()), machine._stream())
+    assert rc == -1  # BN_ERR_INVALID
+    assert "static scratch" in lib.bn_last_error().decode()
+    # without the expected counts only the log-likelihood partial sums need room
+    rc = lib.bn_em_statistics_static(machine._plan, 2, 0, ctypes.c_void_p(ll.data_ptr()), None, machine._stream())
+    assert rc == 0, lib.bn_last_error().decode()
