@@ -21,6 +21,8 @@ cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_bench_c3a_60k.csv
 cd $R
 bash tools/pmc_traffic.sh > $OUT/pmc_traffic.log 2>&1 || { echo "pmc traffic failed"; tail -5 $OUT/pmc_traffic.log; exit 1; }
 cp $R/gpurun_out/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
+bash tools/pmc_valu.sh > $OUT/pmc_valu.log 2>&1 || { echo "pmc valu failed"; tail -5 $OUT/pmc_valu.log; exit 1; }
+cp $R/gpurun_out/pmc_valu.json $OUT/${TAG}_pmc_valu.json
 bash tools/pmc_mfma.sh > $OUT/pmc_mfma.log 2>&1 || { echo "pmc mfma failed"; tail -5 $OUT/pmc_mfma.log; exit 1; }
 cp $R/gpurun_out/pmc_mfma.json $OUT/${TAG}_pmc_mfma_c5.json
 rm -rf $OUT/stats
