@@ -350,7 +350,8 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
         prof_begin(label, bytes, s);
       }
-      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, reduce_last, s);
+      int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, reduce_last, s,
+                                         it == iterations - 2 ? 1 : 0);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
       if (rc == 0) {
         bn::FactorDims fd = make_dims(g.dims);
@@ -1008,9 +1009,11 @@ int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_
   if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // The first iteration can take the evidence straight from the caller's arrays when nothing has
-  // been sent yet, it is not also the last one (that one may have to be re-run later, after the
-  // caller's arrays are gone), and the arrays allow whole-lane loads.
-  bool ingest = !p.observed.empty() && evidence_dev && p.fresh && num_iterations >= 2 && p.N >= 2 &&
+  // been sent yet, it is followed by at least one more loop iteration (the last one may have to be
+  // re-run later, after the caller's arrays are gone, and the one before it is not instantiated
+  // for ingestion), and the arrays allow whole-lane loads (an even number of observations, so that
+  // a lane's pair never straddles the end).
+  bool ingest = !p.observed.empty() && evidence_dev && p.fresh && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0 &&
                 bn::ingest_possible(p);
   if (ingest)
     for (size_t i = 0; i < p.observed.size() && ingest; ++i)
@@ -1039,7 +1042,7 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
   hipStream_t s = static_cast<hipStream_t>(stream);
   // as bn_em_statistics_from; a lane reads its two observations as one 16-bit load, so N must be
   // even and the matrix 2-byte aligned, and every leaf of the ingesting groups must be observed
-  const bool ingest = !p.observed.empty() && states_dev && p.fresh && num_iterations >= 2 && p.N >= 2 &&
+  const bool ingest = !p.observed.empty() && states_dev && p.fresh && num_iterations >= 3 && p.N >= 2 &&
                       p.N % 2 == 0 && reinterpret_cast<uintptr_t>(states_dev) % 2 == 0 &&
                       bn::ingest_states_possible(p);
   if (!ingest) {

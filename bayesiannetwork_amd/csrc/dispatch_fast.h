@@ -6,6 +6,7 @@
 
 #include "launch.h"
 #include "kernels_leaf.h"
+#include "kernels_leaf_loop.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -56,6 +57,12 @@ struct FusedFamily {
   const void** d_src = nullptr;    // [K] evidence source of each leaf for an ingesting launch
   std::vector<const void*> src_on_device;  // what d_src holds
   void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
+  // chunk products of the normalisers: the state between two loop launches of a one-parent group
+  double* zc_mant = nullptr;    // [chunks][npad]
+  int32_t* zc_exp = nullptr;    // [chunks][npad]
+  // which of the two the last loop launch wrote: kZPerFamily (z_state; what full / reduce launches
+  // read), kZPerChunk (zc_*; what the next loop launch reads), kZNone after a reset
+  int32_t z_form = 0;
   void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
   int32_t slots = 0;
   double* ll_part = nullptr;    // [chunks][npad], written by the reduce-mode kernel
@@ -68,6 +75,8 @@ struct FusedFamily {
   int32_t pending_fresh = 0, pending_first = 0;
   bool em_ready = false;  // em_partial holds the counts of the current state
 };
+
+constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2;
 
 struct FastState {
   // normaliser arrays of the nodes no fused family serves (the rest of a log-likelihood sum
@@ -159,6 +168,8 @@ inline void release_fast(Plan& p) {
     if (kv.second.d_src) (void)hipFree(kv.second.d_src);
     if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
     if (kv.second.z_state) (void)hipFree(kv.second.z_state);
+    if (kv.second.zc_mant) (void)hipFree(kv.second.zc_mant);
+    if (kv.second.zc_exp) (void)hipFree(kv.second.zc_exp);
     if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
     if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
@@ -174,6 +185,7 @@ inline void invalidate_fast(Plan& p) {
     for (auto& kv : st->fused) {
       kv.second.pending = false;
       kv.second.em_ready = false;
+      kv.second.z_form = kZNone;
     }
     std::fill(st->root_written.begin(), st->root_written.end(), 0);
   }
@@ -324,7 +336,8 @@ inline int prepare_fast(Plan& p) {
     auto it = st.fused.find(fi);
     if (it == st.fused.end()) return;
     FusedFamily& fam = it->second;
-    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, (void*)fam.d_src, fam.em_partial, fam.z_state, fam.m_state})
+    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, (void*)fam.d_src, fam.em_partial, fam.z_state, fam.m_state,
+                         (void*)fam.zc_mant, (void*)fam.zc_exp})
       if (buffer) (void)hipFree(buffer);
     for (int32_t j : p.fgroups[fi].nodes) handled[j] = 0;
     for (int32_t widx : {fam.wide_index, fam.wide_index2}) {
@@ -451,6 +464,12 @@ inline int prepare_fast(Plan& p) {
       if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.ll_rows_cap * p.npad * sizeof(double)) != hipSuccess)
         return -2;
       p.device_bytes += (int64_t)((size_t)fam.ll_rows_cap * p.npad * sizeof(double));
+      if (fam.wide_index2 < 0) {
+        const size_t zc = (size_t)fam.chunks * p.npad;
+        if (hipMalloc(reinterpret_cast<void**>(&fam.zc_mant), zc * sizeof(double)) != hipSuccess) return -2;
+        if (hipMalloc(reinterpret_cast<void**>(&fam.zc_exp), zc * sizeof(int32_t)) != hipSuccess) return -2;
+        p.device_bytes += (int64_t)(zc * 12);
+      }
     }
   }
   return 0;
@@ -661,17 +680,39 @@ inline LeafFamilyFn<T> leaf_family_for_s(int32_t s) {
   return nullptr;
 }
 
-// two-state leaves only (the ingesting launch)
-template <typename T, int MODE>
-inline LeafFamilyFn<T> leaf_family_lookup_pairs(int32_t d0) {
-  switch (d0) {
-#define X(DV) \
-  case DV:    \
-    return leaf_family_p1<T, DV, 2, kLeafVec, MODE>;
+// loop launches (kernels_leaf_loop.h): the kernel and the dynamic LDS its evidence rings need
+template <typename T>
+struct LeafLoopKernel {
+  LeafFamilyFn<T> fn = nullptr;
+  size_t lds_bytes = 0;
+};
+
+template <typename T, int D0, int OUT, int STATE>
+inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s) {
+  constexpr bool kFromCaller = STATE == kLoopIngest;
+  switch (s) {
+#define X(SV)                                                                                       \
+  case SV:                                                                                          \
+    if constexpr (SV == 2 || (STATE != kLoopIngest && STATE != kLoopIngestStates))                  \
+      return {leaf_loop_p1<T, D0, SV, OUT, STATE>,                                                  \
+              (size_t)kWavesPerBlock * LeafRing<T, SV, kFromCaller>::kWaveBytes};                   \
+    break;
     BN_SMALL_DIMS(X)
 #undef X
   }
-  return nullptr;
+  return {};
+}
+
+template <typename T, int OUT, int STATE>
+inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_loop_for_s<T, DV, OUT, STATE>(s);
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return {};
 }
 
 // reduce-mode launches of two-state leaves with four observations per lane
@@ -703,24 +744,61 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
 template <typename T>
 inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena,
                               const T* cpts, int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s,
-                              bool with_counts = true) {
-  int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
-  if (fresh && mode == kLeafLoop && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next)
-    state = fast_state(p)->ingest_states ? kLeafIngestStates : kLeafIngest;
+                              bool with_counts = true, bool next_is_last = false) {
+  const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+  const bool ingest_wanted = fresh && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next;
   LeafFamilyFn<T> fn = nullptr;
-  switch (mode + 3 * state) {
-    case kLeafLoop + 3 * kLeafIngest:
-      fn = leaf_family_lookup_pairs<T, kLeafLoop + 3 * kLeafIngest>(g.dims[0]);
-      break;
-    case kLeafLoop + 3 * kLeafIngestStates:
-      fn = leaf_family_lookup_pairs<T, kLeafLoop + 3 * kLeafIngestStates>(g.dims[0]);
-      break;
-#define X(M)                                                                                                    \
-  case M:                                                                                                       \
-    fn = w2 ? leaf_family_p2<T, 2, 2, 2, kLeafVec, M> : leaf_family_lookup<T, M>(g.dims[0], g.dims[1]);         \
+  size_t lds_bytes = 0;
+  const bool loop_p1 = mode == kLeafLoop && !w2;
+  int32_t loop_out = kLoopLight;
+  if (loop_p1) {
+    // one-parent loop launch: the launch before a full / reduce launch leaves one z per family,
+    // any earlier one the chunk products of the z
+    loop_out = next_is_last ? kLoopLast : kLoopLight;
+    int32_t from = fresh ? kLoopFresh : (first_iteration ? kLoopFromArrays : kLoopChunk);
+    if (ingest_wanted) {
+      if (loop_out != kLoopLight) return -1;  // callers ask for ingestion only with a loop launch to spare
+      from = fast_state(p)->ingest_states ? kLoopIngestStates : kLoopIngest;
+    }
+    if (from == kLoopChunk && fam.z_form != kZPerChunk) return -1;
+    LeafLoopKernel<T> k;
+    switch (loop_out * 8 + from) {
+#define X(OUT, FROM)                                                      \
+  case OUT * 8 + FROM:                                                    \
+    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1]);             \
     break;
-    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+      X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
+      X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates)
+      X(kLoopLast, kLoopChunk) X(kLoopLast, kLoopFresh) X(kLoopLast, kLoopFromArrays)
 #undef X
+    }
+    fn = k.fn;
+    lds_bytes = k.lds_bytes;
+    if (fn && lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return -1;
+  } else if (w2) {
+    if (ingest_wanted) return -1;
+    switch (mode + 3 * state) {
+#define X(M) \
+  case M:    \
+    fn = leaf_family_p2<T, 2, 2, 2, kLeafVec, M>; \
+    break;
+      X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+    }
+  } else {
+    if (ingest_wanted) return -1;  // the evidence would never reach the arena
+    if (state == kLeafSteady && fam.z_form != kZPerFamily) return -1;
+    switch (mode + 3 * state) {
+#define X(M) \
+  case M:    \
+    fn = leaf_family_lookup<T, M>(g.dims[0], g.dims[1]); \
+    break;
+      X(1) X(2) X(4) X(5) X(7) X(8)
+#undef X
+    }
   }
   // Reduce mode writes no partial products, so it is free to cut the families differently: with
   // four observations per lane (one wave per tile and chunk) the count sums cross the lanes half
@@ -764,6 +842,8 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.ntiles = p.ntiles;
   a.N = p.N;
   a.z_state = static_cast<T*>(fam.z_state);
+  a.zc_mant = fam.zc_mant;
+  a.zc_exp = fam.zc_exp;
   a.em_partial = with_counts ? static_cast<T*>(fam.em_partial) : nullptr;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
@@ -782,8 +862,9 @@ inline int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     a.slots = (int32_t)p.ntiles;
     waves = (int64_t)a.chunks * p.ntiles;
   }
-  launch(fn, dim3(wave_blocks(waves)), dim3(256), 0, s, arena, cpts, a);
+  launch(fn, dim3(wave_blocks(waves)), dim3(256), lds_bytes, s, arena, cpts, a);
   if (!launch_ok()) return -1;
+  if (loop_p1) fam.z_form = loop_out == kLoopLast ? kZPerFamily : kZPerChunk;
   if (mode == kLeafReduce) {
     fam.ll_rows = a.chunks;
     fam.slots_used = a.slots;
@@ -886,7 +967,7 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
 
 template <typename T>
 int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t first_iteration,
-                       int32_t last_iteration, int32_t reduce_last, hipStream_t s) {
+                       int32_t last_iteration, int32_t reduce_last, hipStream_t s, int32_t next_is_last = 0) {
   FastState* st = fast_state(p);
   const size_t fi = (size_t)(&g - p.fgroups.data());
   if (st) {
@@ -897,7 +978,7 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
       // reduce_last == 2: only the log-likelihood sums are wanted from the reduce-mode launch
       return launch_leaf_family<T>(p, g, it->second, w, w2, arena_t, cpts_t, fresh, first_iteration, mode, s,
-                                   reduce_last != 2);
+                                   reduce_last != 2, next_is_last != 0);
     }
   }
   {

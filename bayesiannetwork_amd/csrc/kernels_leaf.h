@@ -24,6 +24,10 @@ struct LeafFamilyArgs {
   int64_t npad;
   int64_t ntiles;
   T* z_state;  // [K][npad] loop state: the leaf's normaliser z for the coming iteration
+  // loop state between two loop launches (leaf_loop_p1): prod_k z_k over each chunk's families,
+  // per observation, as mantissa in [0.5, 1) and exponent
+  double* zc_mant;   // [chunks][npad]
+  int32_t* zc_exp;   // [chunks][npad]
   // kLeafReduce only
   int64_t N;
   T* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable); nullptr = not wanted
@@ -35,13 +39,14 @@ struct LeafFamilyArgs {
   int32_t* part_exp2;
   const double* scaled2;
   T* m_state;  // [K][D0 + D1][npad]
-  // kLeafIngest only: per family, the caller's evidence array ([N][2], row-major) of its leaf, or
-  // the leaf's stand-in observation array in the arena (all ones) when it is not observed
+  // ingesting loop launches only: per family, the caller's evidence array ([N][2], row-major) of its
+  // leaf, or the leaf's stand-in observation array in the arena (all ones) when it is not observed
   const void* const* src;
-  T on_value, off_value;  // kLeafIngestStates: what an observed / any other state's row receives
+  T on_value, off_value;  // evidence given as states: what an observed / any other state's row receives
 };
 // Template parameter MODE
-//   kLeafLoop    inside a bn_iterate call: only the loop state (the next z) is written;
+//   kLeafLoop    inside a bn_iterate call: only the loop state is written (one-parent families run
+//                these launches on leaf_loop_p1, kernels_leaf_loop.h; leaf_family_p2 has the mode);
 //   kLeafFull    last iteration of a bn_iterate call: everything queries may read is written
 //                (both variable -> factor messages, the message to the parent, c = log z);
 //   kLeafReduce  last iteration of an EM step (bn_em_statistics): nothing of the message state is
@@ -54,12 +59,7 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 //   kLeafSteady      the loop state a kLeafLoop launch left (z_state);
 //   kLeafFresh       nothing has been sent yet: every message still has its initial uniform value;
 //   kLeafFromArrays  the message arrays a kLeafFull launch wrote.
-//   kLeafIngest      as kLeafFresh, and the observations have not been copied into the arena yet:
-//                    they are read from the caller's arrays and the arena copy is written on the
-//                    way (two-state leaves, two observations per lane, kLeafLoop only).
-//   kLeafIngestStates  as kLeafIngest, from compact hard evidence: one uint8 state per observation
-//                    (bn_enter_evidence_states' format); the arena copy holds on_value / off_value.
-constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafIngest = 3, kLeafIngestStates = 4;
+constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -158,7 +158,6 @@ struct LeafPtrs {  // wave-uniform
   T* z;          // loop-state normaliser of this family
   const T* obs;  // the observation, or an all-ones array when the leaf is not observed
   const T* cpt;
-  const T* src;  // ingesting launches: the caller's evidence array of this leaf (== obs when not observed)
 };
 
 template <typename T, int S, int V>
@@ -167,7 +166,7 @@ struct LeafState {
   fv<T, V> z;  // the leaf's normaliser for this iteration: sum_s ev[s] * (previous message from the factor)[s]
 };
 
-template <typename T, int INGEST = 0>
+template <typename T>
 __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T* __restrict__ cpts,
                                                  const LeafFamilyArgs<T>& a, int32_t k) {
   LeafPtrs<T> p;
@@ -179,8 +178,6 @@ __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T*
   p.z = a.z_state + (int64_t)k * a.npad;
   p.obs = arena + a.obs_off[k];
   p.cpt = cpts + a.cpt_off[k];
-  p.src = nullptr;
-  if constexpr (INGEST != 0) p.src = static_cast<const T*>(a.src[k]);
   return p;
 }
 
@@ -200,47 +197,12 @@ __device__ __forceinline__ fv<T, V> recipv(const fv<T, V>& x) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, splat<T, V>(1.f)), r, r);
 }
 
-template <typename T, int S, int V, int STATE, int INGEST = 0>
+template <typename T, int S, int V, int STATE>
 __device__ __forceinline__ LeafState<T, S, V> leaf_state(const LeafPtrs<T>& p, const LeafFamilyArgs<T>& a, int64_t t,
                                                       int32_t col) {
   LeafState<T, S, V> st;
-  if constexpr (INGEST == 2 && S == 2 && V == 2) {
-    // compact hard evidence: this lane's two observations are two consecutive bytes (N is even,
-    // so a lane's pair never straddles the end except as a whole)
-    const int64_t n0 = t * tile_of<T>::value + col;
-    const bool tail = n0 + 1 >= a.N;
-    const int64_t at = tail ? a.N - 2 : n0;
-    const uint32_t pair = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(p.src) + at);
-    const uint32_t s0 = pair & 0xffu, s1 = pair >> 8;
-    st.ev[0][0] = s0 == 0 ? a.on_value : a.off_value;
-    st.ev[1][0] = s0 == 1 ? a.on_value : a.off_value;
-    st.ev[0][1] = s1 == 0 ? a.on_value : a.off_value;
-    st.ev[1][1] = s1 == 1 ? a.on_value : a.off_value;
-    T* dst = const_cast<T*>(p.obs);
-    storev<T, V>(dst, t * S, col, st.ev[0]);
-    storev<T, V>(dst, t * S + 1, col, st.ev[1]);
-  } else if constexpr (INGEST == 1 && S == 2 && V == 2) {
-    // This lane's two observations are four consecutive elements of the caller's [N][2] array
-    // (an unobserved leaf reads the all-ones array instead).  Branch-free: a lane whose second
-    // observation lies beyond N loads the array's last four elements and takes the last pair as
-    // its first observation; what padding observations hold does not matter.
-    const int64_t n0 = t * tile_of<T>::value + col;
-    const bool tail = n0 + 1 >= a.N;
-    const int64_t at = tail ? a.N - 2 : n0;
-    const fv<T, 4> raw = *reinterpret_cast<const fv<T, 4>*>(p.src + at * 2);
-    st.ev[0][0] = tail ? raw[2] : raw[0];
-    st.ev[1][0] = tail ? raw[3] : raw[1];
-    st.ev[0][1] = raw[2];
-    st.ev[1][1] = raw[3];
-    // The arena copy.  Unconditional (a branch here costs the loop its register budget): an
-    // unobserved leaf writes the ones it has just read back into the shared all-ones array.
-    T* dst = const_cast<T*>(p.obs);
-    storev<T, V>(dst, t * S, col, st.ev[0]);
-    storev<T, V>(dst, t * S + 1, col, st.ev[1]);
-  } else {
 #pragma unroll
-    for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
-  }
+  for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
   if constexpr (STATE != kLeafSteady) {
     fv<T, V> own[S];
 #pragma unroll
@@ -265,8 +227,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
                                                      LeafFamilyArgs<T> a) {
   constexpr bool FULL = MODE % 3 == kLeafFull;
   constexpr bool REDUCE = MODE % 3 == kLeafReduce;
-  constexpr int32_t INGEST = MODE / 3 == kLeafIngest ? 1 : (MODE / 3 == kLeafIngestStates ? 2 : 0);
-  constexpr int32_t STATE = INGEST != 0 ? kLeafFresh : MODE / 3;
+  static_assert(FULL || REDUCE, "loop launches of one-parent families run on leaf_loop_p1");
+  constexpr int32_t STATE = MODE / 3;
   constexpr int32_t kParts = tile_of<T>::value / (64 * V);
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -318,11 +280,7 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     }
   }
 
-  // loop mode keeps the leaves' normalisers out of the per-state products: prod_k (q_k / z_k) is
-  // carried as prod_k q_k per state and prod_k z_k per observation, divided once at the end
-  fv<T, V> pf_sum = pf[0];
-#pragma unroll
-  for (int32_t i = 1; i < D0; ++i) pf_sum += pf[i];
+  // reduce mode: prod_k z_k per observation (one log at the end gives sum_k log z_k)
   double pz[V];
   int32_t pze[V];
 #pragma unroll
@@ -331,12 +289,12 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     pze[v] = 0;
   }
 
-  LeafPtrs<T> ptr = leaf_ptrs<T, INGEST>(arena, cpts, a, first);
-  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE, INGEST>(ptr, a, t, col);
+  LeafPtrs<T> ptr = leaf_ptrs<T>(arena, cpts, a, first);
+  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
     const int32_t kn = k + 1 < last ? k + 1 : k;
-    const LeafPtrs<T> ptr_next = leaf_ptrs<T, INGEST>(arena, cpts, a, kn);
-    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE, INGEST>(ptr_next, a, t, col);
+    const LeafPtrs<T> ptr_next = leaf_ptrs<T>(arena, cpts, a, kn);
+    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE>(ptr_next, a, t, col);
     const T* cpt = ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the
@@ -366,49 +324,6 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       inv_sum += r[i];
     }
     inv_sum = rcpv<T, V>(inv_sum);
-    if constexpr (!FULL && !REDUCE) {
-      // Loop mode needs neither message explicitly.  The leaf's next normaliser is
-      //   z' = sum_s ev[s] * (cpt^T t)[s] = sum_i t[i] * q[i],  t = r / sum r,
-      // which in the steady state (r = P'/q) is sum(P') / sum(r).
-      fv<T, V> zn;
-      if constexpr (STATE == kLeafSteady) {
-        zn = pf_sum * inv_sum;
-      } else {
-        zn = r[0] * q[0];
-#pragma unroll
-        for (int32_t i = 1; i < D0; ++i) zn = __builtin_elementwise_fma(r[i], q[i], zn);
-        zn *= inv_sum;
-      }
-      storev<T, V>(ptr.z, t, col, zn);
-#pragma unroll
-      for (int32_t v = 0; v < V; ++v) {
-#pragma unroll
-        for (int32_t i = 0; i < D0; ++i) pm[i][v] *= (double)q[i][v];
-        pz[v] *= (double)cur.z[v];
-      }
-      if (renorm_due<T>(k - first + 1)) {
-#pragma unroll
-        for (int32_t i = 0; i < D0; ++i) {
-          ev_t<V> de_v;
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v) {
-            int de = 0;
-            pm[i][v] = frexp(pm[i][v], &de);
-            de_v[v] = de;
-          }
-          pe[i] += de_v;
-        }
-#pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          int de = 0;
-          pz[v] = frexp(pz[v], &de);
-          pze[v] += de;
-        }
-      }
-      ptr = ptr_next;
-      cur = nxt;
-      continue;
-    }
     if constexpr (REDUCE) {
       // sum_k log z_k = log prod_k z_k: the product is carried like in loop mode, one log at the end
 #pragma unroll

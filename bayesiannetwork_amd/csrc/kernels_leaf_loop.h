@@ -1,0 +1,372 @@
+// Loop launches of the one-parent leaf-family scheme (see kernels_wide.h / kernels_leaf.h): the
+// iterations of a bn_iterate / bn_em_statistics call that are not the last one.  Such a launch
+// writes nothing a query could read, only the state the next iteration starts from.
+//
+// What differs from leaf_family_p1:
+//   * The evidence of the chunk's families reaches the wave through a private ring of LDS slots
+//     filled by LDS-DMA (global_load_lds_dwordx4): several families are in flight per wave without
+//     holding registers, so HBM latency hides behind the arithmetic at four waves per SIMD.
+//   * Per-family table entries and CPT rows are read with scalar loads one family ahead.
+//   * The leaves' normalisers z_k are only needed as their product over the chunk (it scales the
+//     parent's partial product).  A launch that is followed by another loop launch (kLoopLight)
+//     therefore writes prod_k z_k per (chunk, observation) - mantissa and exponent - instead of
+//     one z per family and observation; only the launch before a full / reduce launch
+//     (kLoopLast) writes every z, which those kernels read.
+#pragma once
+
+#include "kernels_leaf.h"
+
+namespace bn {
+
+constexpr int32_t kLoopLight = 0, kLoopLast = 1;
+// where the iteration's input state comes from
+//   kLoopChunk         a kLoopLight launch: chunk products of the normalisers (zc_mant / zc_exp)
+//   kLoopFresh         nothing has been sent yet (uniform messages)
+//   kLoopFromArrays    the message arrays a full launch wrote
+//   kLoopIngest        as kLoopFresh, evidence read from the caller's [N][2] arrays and copied into
+//                      the arena on the way (two-state leaves)
+//   kLoopIngestStates  as kLoopIngest, from one uint8 state per observation
+constexpr int32_t kLoopChunk = 0, kLoopFresh = 1, kLoopFromArrays = 2, kLoopIngest = 3, kLoopIngestStates = 4;
+
+typedef const __attribute__((address_space(4))) int64_t* const_table_ptr;  // read through the scalar cache
+
+// One LDS-DMA instruction: lane l moves 16 bytes from base + voff(l) to LDS byte address lds_dst + 16 l.
+// The compiler does not count it: its completion is waited for with wait_vmcnt below.
+__device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_dst), "s"(base)
+      : "memory");
+}
+
+// Waits until at most N of the wave's vector-memory operations are outstanding (they complete in
+// issue order, so everything but the N youngest has arrived).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// frexp of a non-negative double in place; returns the exponent (0 for 0)
+__device__ __forceinline__ int32_t frexp_in_place(double& x) {
+  int32_t e;
+  asm("v_frexp_exp_i32_f64_e32 %0, %1" : "=v"(e) : "v"(x));
+  asm("v_frexp_mant_f64_e32 %0, %0" : "+v"(x));
+  return e;
+}
+
+// Geometry of the evidence ring for element type T and S states (two observations per lane).
+template <typename T, int S, bool FROM_CALLER>
+struct LeafRing {
+  static constexpr int32_t kRowBytes = 64 * 2 * (int32_t)sizeof(T);        // one state row of the wave's observations
+  static constexpr int32_t kFamilyBytes = S * kRowBytes;                    // the same bytes in the caller's [N][S] layout
+  static constexpr int32_t kDmas = (kFamilyBytes + 1023) / 1024;            // DMA instructions per family
+  static constexpr int32_t kSlotBytes = kDmas * 1024;
+  static constexpr int32_t kDepth = 8192 / kSlotBytes >= 8 ? 8 : (8192 / kSlotBytes >= 2 ? 8192 / kSlotBytes : 2);
+  static constexpr int32_t kWaveBytes = kDepth * kSlotBytes;
+};
+
+template <typename T, int D0, int S, int OUT, int STATE>
+__global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const T* __restrict__ cpts,
+                                                   LeafFamilyArgs<T> a) {
+  constexpr int32_t V = 2;
+  constexpr bool LAST = OUT == kLoopLast;
+  constexpr bool INGEST = STATE == kLoopIngest, INGEST_STATES = STATE == kLoopIngestStates;
+  constexpr bool FRESH = STATE == kLoopFresh || INGEST || INGEST_STATES;
+  static_assert(!(INGEST || INGEST_STATES) || S == 2, "evidence is taken from the caller's arrays for two-state leaves only");
+  using Ring = LeafRing<T, S, INGEST>;
+  constexpr int32_t R = Ring::kDepth, ND = Ring::kDmas;
+  // vector-memory operations issued per family besides the DMAs (they sit between the DMAs in the
+  // queue, so the counted waits allow for them): the z store of kLoopLast, the arena copy of the
+  // evidence when ingesting
+  constexpr int32_t kOther = (LAST ? 1 : 0) + ((INGEST || INGEST_STATES) ? S : 0);
+  constexpr int32_t kAhead = (R - 1) * (ND + kOther);
+  constexpr int32_t kParts = tile_of<T>::value / (64 * V);
+  constexpr int32_t E = D0 * S;
+  extern __shared__ __align__(16) unsigned char ring_raw[];
+
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
+  const int32_t part = (int32_t)(w % kParts);
+  w /= kParts;
+  const int32_t chunk = (int32_t)(w / a.ntiles);
+  const int64_t t = w % a.ntiles;
+  const int32_t col = part * 64 * V + lane * V;  // first observation of this lane inside the tile
+  const int64_t obs0 = t * tile_of<T>::value + col;
+  const int32_t first = chunk * a.chunk_len;
+  const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
+  if (first >= last) return;
+  const int32_t n = last - first;
+
+  const_table_ptr obs_tab = (const_table_ptr)a.obs_off;
+  const_table_ptr cpt_tab = (const_table_ptr)a.cpt_off;
+  const_table_ptr src_tab = (const_table_ptr)a.src;
+
+  // Byte offset, from the start of a family's evidence, of the 16 bytes this lane fetches in each
+  // of the family's DMA instructions.  Arena layout: [tile][state][observation]; the wave's piece of
+  // state row r is kRowBytes long.  Caller layout: [observation][state], the wave's observations
+  // are one contiguous run (clamped at the end of the array: padding observations read real ones).
+  uint32_t voff[ND];
+#pragma unroll
+  for (int32_t j = 0; j < ND; ++j) {
+    const int32_t at = j * 1024 + lane * 16;  // byte within the slot
+    if constexpr (INGEST) {
+      int64_t byte = (t * tile_of<T>::value + part * 64 * V) * (int64_t)(S * sizeof(T)) + at;
+      const int64_t end = a.N * (int64_t)(S * sizeof(T)) - 16;
+      byte = byte < end ? byte : end;
+      voff[j] = (uint32_t)byte;
+    } else {
+      int32_t row = at / Ring::kRowBytes;
+      row = row < S ? row : S - 1;
+      voff[j] = (uint32_t)(((t * S + row) * tile_of<T>::value + part * 64 * V) * (int64_t)sizeof(T) + at % Ring::kRowBytes);
+    }
+  }
+  const uint32_t ring = (uint32_t)(uintptr_t)ring_raw + (uint32_t)wave * Ring::kWaveBytes;
+  const unsigned char* my_ring = ring_raw + wave * Ring::kWaveBytes;
+  auto family_source = [&](int32_t k) -> const void* {
+    if constexpr (INGEST) return reinterpret_cast<const void*>(src_tab[k]);
+    return arena + obs_tab[k];
+  };
+  auto request = [&](const void* source, int32_t slot) {
+#pragma unroll
+    for (int32_t j = 0; j < ND; ++j) lds_dma16(source, voff[j], ring + (uint32_t)(slot * Ring::kSlotBytes + j * 1024));
+  };
+  // this lane's evidence of the family in `slot`
+  auto read_slot = [&](int32_t slot, fv<T, V>* ev) {
+    const unsigned char* p = my_ring + slot * Ring::kSlotBytes;
+    if constexpr (INGEST) {
+      // [observation][state]: two observations x two states are consecutive
+      const fv<T, 4> raw = *reinterpret_cast<const fv<T, 4>*>(p + lane * (4 * sizeof(T)));
+      ev[0][0] = raw[0];
+      ev[1][0] = raw[1];
+      ev[0][1] = raw[2];
+      ev[1][1] = raw[3];
+    } else {
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+        ev[j] = *reinterpret_cast<const fv<T, V>*>(p + j * Ring::kRowBytes + lane * (V * sizeof(T)));
+    }
+  };
+  // compact hard evidence: this lane's two observations are two consecutive bytes (N is even)
+  auto states_pair = [&](int32_t k) -> uint32_t {
+    const bool tail = obs0 + 1 >= a.N;
+    const int64_t at = tail ? a.N - 2 : obs0;
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(src_tab[k]) + at);
+  };
+  auto expand_states = [&](uint32_t pair, fv<T, V>* ev) {
+    const uint32_t s0 = pair & 0xffu, s1 = pair >> 8;
+    ev[0][0] = s0 == 0 ? a.on_value : a.off_value;
+    ev[1][0] = s0 == 1 ? a.on_value : a.off_value;
+    ev[0][1] = s1 == 0 ? a.on_value : a.off_value;
+    ev[1][1] = s1 == 1 ? a.on_value : a.off_value;
+  };
+
+  double pm[D0][V];
+  ev_t<V> pe[D0];
+#pragma unroll
+  for (int32_t s = 0; s < D0; ++s)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      pm[s][v] = 1.0;
+      pe[s][v] = 0;
+    }
+  // the parent's scaled product P' (largest state = 1) for this lane's observations, in T
+  fv<T, V> pf[D0];
+#pragma unroll
+  for (int32_t i = 0; i < D0; ++i) {
+    const double2 lo = *reinterpret_cast<const double2*>(a.scaled + (int64_t)i * a.npad + obs0);
+    pf[i][0] = (T)lo.x;
+    pf[i][1] = (T)lo.y;
+  }
+  fv<T, V> pf_sum = pf[0];
+#pragma unroll
+  for (int32_t i = 1; i < D0; ++i) pf_sum += pf[i];
+  // prod_k z_k of this iteration (read, or multiplied up below) and of the next one
+  double zin_m[V] = {1.0, 1.0};
+  int32_t zin_e[V] = {0, 0};
+  if constexpr (STATE == kLoopChunk) {
+    const double2 m = *reinterpret_cast<const double2*>(a.zc_mant + (int64_t)chunk * a.npad + obs0);
+    const int2 e = *reinterpret_cast<const int2*>(a.zc_exp + (int64_t)chunk * a.npad + obs0);
+    zin_m[0] = m.x;
+    zin_m[1] = m.y;
+    zin_e[0] = e.x;
+    zin_e[1] = e.y;
+  }
+  double pz[V] = {1.0, 1.0};
+  int32_t pze[V] = {0, 0};
+
+  // the loads above have arrived before the first DMA is counted
+  wait_vmcnt<0>();
+  fv<T, V> cur_ev[S], nxt_ev[S];
+  uint32_t nxt_pair = 0;
+  if constexpr (INGEST_STATES) {
+    expand_states(states_pair(first), cur_ev);
+  } else {
+    for (int32_t i = 0; i < R && i < n; ++i) request(family_source(first + i), i);
+    if (n >= R) {
+      wait_vmcnt<(R - 1) * ND>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    read_slot(0, cur_ev);
+  }
+  // table entries and CPT rows travel one family ahead through the scalar cache
+  int64_t ahead_off = 0;
+  if constexpr (!INGEST_STATES) {
+    const int32_t ka = first + R < last ? first + R : last - 1;
+    ahead_off = INGEST ? src_tab[ka] : obs_tab[ka];
+  }
+  int64_t cpt_next_off = cpt_tab[first + 1 < last ? first + 1 : first];
+  T cpt_cur[E];
+  {
+    const T* c = cpts + cpt_tab[first];
+#pragma unroll
+    for (int32_t j = 0; j < E; ++j) cpt_cur[j] = c[j];
+  }
+  int32_t until_renorm = sizeof(T) == 8 ? 1 : 6;  // six float factors cannot leave the double range
+
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t k = first + i;
+    T cpt_nxt[E];
+    {
+      const T* c = cpts + cpt_next_off;
+#pragma unroll
+      for (int32_t j = 0; j < E; ++j) cpt_nxt[j] = c[j];
+    }
+    cpt_next_off = cpt_tab[k + 2 < last ? k + 2 : last - 1];
+    const int32_t in = i + 1 < n ? i + 1 : i;
+    if constexpr (INGEST_STATES) {
+      nxt_pair = states_pair(first + in);
+    } else {
+      if (i + R < n) {
+        // the slot of family i is free once its evidence is in registers
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) asm volatile("" ::"v"(cur_ev[j]));
+        const void* source = INGEST ? reinterpret_cast<const void*>(ahead_off) : static_cast<const void*>(arena + ahead_off);
+        request(source, i % R);
+        const int32_t ka = k + R + 1 < last ? k + R + 1 : last - 1;
+        ahead_off = INGEST ? src_tab[ka] : obs_tab[ka];
+        wait_vmcnt<kAhead>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      read_slot(in % R, nxt_ev);
+    }
+    if constexpr (INGEST || INGEST_STATES) {
+      // the arena copy of the evidence (an unobserved leaf rewrites the shared all-ones array)
+      T* dst = arena + obs_tab[k];
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) storev<T, V>(dst, t * S + j, col, cur_ev[j]);
+    }
+
+    // q = cpt . ev: the factor's message to the parent is q / z, and q also stands in for the
+    // previous such message in the parent's emission (which is normalised over the states)
+    fv<T, V> q[D0];
+#pragma unroll
+    for (int32_t d = 0; d < D0; ++d) {
+      q[d] = cpt_cur[d * S] * cur_ev[0];
+#pragma unroll
+      for (int32_t j = 1; j < S; ++j) q[d] = __builtin_elementwise_fma(splat<T, V>(cpt_cur[d * S + j]), cur_ev[j], q[d]);
+    }
+    // this iteration's z of the leaf where it is not part of the state that was read
+    if constexpr (STATE != kLoopChunk) {
+      fv<T, V> own[S];
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j)
+        own[j] = FRESH ? splat<T, V>((T)1 / (T)S) : loadv<T, V>(arena + a.f_out[2 * k + 1], t * S + j, col);
+      const fv<T, V> z = leaf_normaliser<T, S, V>(cur_ev, own);
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) zin_m[v] *= (double)z[v];
+    }
+    // the leaf's next normaliser z' = sum_i t_i q_i with t = r / sum r, r = P' / (previous message
+    // to the parent); in the steady state r = P' / q and z' = sum(P') / sum(r)
+    fv<T, V> zn;
+    if constexpr (STATE == kLoopChunk) {
+      fv<T, V> sum_r = splat<T, V>(0.f);
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) sum_r = __builtin_elementwise_fma(pf[d], rcpv<T, V>(q[d]), sum_r);
+      zn = pf_sum * rcpv<T, V>(sum_r);
+    } else {
+      fv<T, V> sum_r = splat<T, V>(0.f), acc = splat<T, V>(0.f);
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        const fv<T, V> prev = FRESH ? splat<T, V>((T)1 / (T)D0) : loadv<T, V>(arena + a.f_out[2 * k], t * D0 + d, col);
+        const fv<T, V> r = pf[d] * rcpv<T, V>(prev);
+        sum_r += r;
+        acc = __builtin_elementwise_fma(r, q[d], acc);
+      }
+      zn = acc * rcpv<T, V>(sum_r);
+    }
+    if constexpr (LAST) storev<T, V>(a.z_state + (int64_t)k * a.npad, t, col, zn);
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) pm[d][v] *= (double)q[d][v];
+      if constexpr (!LAST) pz[v] *= (double)zn[v];
+    }
+    if (--until_renorm == 0) {
+      until_renorm = sizeof(T) == 8 ? 1 : 6;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        ev_t<V> de_v;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) de_v[v] = frexp_in_place(pm[d][v]);
+        pe[d] += de_v;
+      }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        if constexpr (!LAST) pze[v] += frexp_in_place(pz[v]);
+        if constexpr (STATE != kLoopChunk) zin_e[v] += frexp_in_place(zin_m[v]);
+      }
+    }
+    if constexpr (INGEST_STATES) {
+      expand_states(nxt_pair, cur_ev);
+    } else {
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) cur_ev[j] = nxt_ev[j];
+    }
+#pragma unroll
+    for (int32_t j = 0; j < E; ++j) cpt_cur[j] = cpt_nxt[j];
+  }
+  if constexpr (!LAST) {
+    double2 m;
+    int2 e;
+    int de = 0;
+    m.x = frexp(pz[0], &de);
+    e.x = pze[0] + de;
+    m.y = frexp(pz[1], &de);
+    e.y = pze[1] + de;
+    *reinterpret_cast<double2*>(a.zc_mant + (int64_t)chunk * a.npad + obs0) = m;
+    *reinterpret_cast<int2*>(a.zc_exp + (int64_t)chunk * a.npad + obs0) = e;
+  }
+  // the chunk's partial product of the messages to the parent: prod q / prod z
+  double inv_z[V];
+#pragma unroll
+  for (int32_t v = 0; v < V; ++v) {
+    int de = 0;
+    inv_z[v] = 1.0 / frexp(zin_m[v], &de);
+    zin_e[v] += de;
+  }
+#pragma unroll
+  for (int32_t s = 0; s < D0; ++s) {
+    int32_t ex[V];
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      pm[s][v] = frexp(pm[s][v] * inv_z[v], &de);
+      ex[v] = (int32_t)pe[s][v] + de - zin_e[v];
+    }
+    const int64_t row = ((int64_t)(a.chunk_base + chunk) * D0 + s) * a.npad + obs0;
+    *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
+    *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(ex[0], ex[1]);
+  }
+}
+
+}  // namespace bn

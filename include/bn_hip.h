@@ -195,7 +195,7 @@ int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t avera
 /*
  * bn_enter_evidence followed by bn_em_statistics, as one call: same arguments, same results, same
  * state afterwards (the observation slots hold the evidence).  When nothing has been sent since
- * the last reset, at least two iterations are asked for, every observed node is a two-state leaf
+ * the last reset, at least three iterations are asked for, num_observations is even, every observed node is a two-state leaf
  * served by a fused leaf-family kernel and the evidence arrays are 32-byte aligned, the first
  * iteration reads the evidence from the caller's arrays and writes the plan's copy on the way,
  * which saves the separate copy pass; otherwise it is literally the two calls.  The evidence
@@ -209,8 +209,8 @@ int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_
 /*
  * The same for compact hard evidence: bn_enter_evidence_states followed by bn_em_statistics, as
  * one call (arguments of both).  The first iteration reads the state bytes itself and writes the
- * observation slots on the way when, in addition to the conditions above, num_observations is
- * even and every leaf of the fused groups is observed; otherwise it is literally the two calls.
+ * observation slots on the way when, in addition to the conditions above, every leaf of the fused
+ * groups is observed; otherwise it is literally the two calls.
  */
 int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
                                  int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,

@@ -43,6 +43,9 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
       if (OP == 15) { asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(e[i])); }
       if (OP == 16) { asm volatile("v_exp_f32_e32 %0, %0" : "+v"(a[i])); }
       if (OP == 17) { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c0)); }
+      if (OP == 18) { asm volatile("v_rcp_f32_e32 %0, %0\n\tv_mul_f64 %1, %1, %2" : "+v"(a[i]), "+v"(d[i]) : "v"(d[(i + 1) & 7])); }
+      if (OP == 19) { asm volatile("v_rcp_f32_e32 %0, %0\n\tv_pk_fma_f32 %1, %1, %2, %3" : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1)); }
+      if (OP == 20) { asm volatile("v_rcp_f32_e32 %0, %0\n\tv_cvt_f64_f32_e32 %1, %3\n\tv_mul_f64 %2, %2, %1" : "+v"(a[i]), "=&v"(d[(i + 1) & 7]), "+v"(d[i]) : "v"(a[(i + 2) & 7])); }
     }
   }
   float acc = 0;
@@ -72,16 +75,16 @@ int main() {
   const char* names[] = {"v_fma_f32", "v_rcp_f32", "v_fma_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_frexp_mant_f64",
                          "v_frexp_exp_i32_f64", "v_mul_f64", "v_log_f32 (+add)", "v_pk_fma_f32", "v_pk_mul_f32",
                          "v_mov_b64", "v_frexp_mant_f32", "v_mul_hi_u32", "v_mul_f32", "v_ldexp_f64", "v_exp_f32",
-                         "v_pk_add_f32"};
+                         "v_pk_add_f32", "rcp_f32 + mul_f64", "rcp_f32 + pk_fma_f32", "rcp + cvt + mul_f64"};
   for (int w : {1, 4, 8}) {
-    float ms[18];
+    float ms[21];
     ms[0] = run<0>(out, w); ms[1] = run<1>(out, w); ms[2] = run<2>(out, w); ms[3] = run<3>(out, w);
     ms[4] = run<4>(out, w); ms[5] = run<5>(out, w); ms[6] = run<6>(out, w); ms[7] = run<7>(out, w);
     ms[8] = run<8>(out, w); ms[9] = run<9>(out, w); ms[10] = run<10>(out, w); ms[11] = run<11>(out, w);
     ms[12] = run<12>(out, w); ms[13] = run<13>(out, w); ms[14] = run<14>(out, w); ms[15] = run<15>(out, w);
-    ms[16] = run<16>(out, w); ms[17] = run<17>(out, w);
+    ms[16] = run<16>(out, w); ms[17] = run<17>(out, w); ms[18] = run<18>(out, w); ms[19] = run<19>(out, w); ms[20] = run<20>(out, w);
     // cycles per wave-instruction on one SIMD at ~2.4 GHz: ms * 2.4e6 / (ITERS * 8 instr * waves per SIMD)
-    for (int i = 0; i < 18; ++i)
+    for (int i = 0; i < 21; ++i)
       printf("waves/SIMD %d  %-22s %8.3f ms  x%.2f of fma_f32  ~%.2f cyc per wave-instruction\n", w, names[i], ms[i],
              ms[i] / ms[0], ms[i] * 2.4e6 / (ITERS * 8.0 * w));
   }
