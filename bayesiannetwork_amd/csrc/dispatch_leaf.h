@@ -1,0 +1,231 @@
+// Launching the leaf-family kernels: which instantiation serves a launch, its geometry and the
+// bookkeeping of the loop state.  Included by the translation units that instantiate these kernels
+// (leaf_f32.hip, leaf_f64.hip); everybody else sees launch_leaf_family through dispatch_fast.h.
+#pragma once
+
+#include <algorithm>
+
+#include "fast_state.h"
+#include "kernels_leaf.h"
+#include "kernels_leaf_loop.h"
+#include "launch.h"
+
+namespace bn {
+
+template <typename T>
+using LeafFamilyFn = void (*)(T*, const T*, LeafFamilyArgs<T>);
+
+template <typename T, int D0, int MODE>
+inline LeafFamilyFn<T> leaf_family_for_s(int32_t s) {
+  switch (s) {
+#define X(SV) \
+  case SV:    \
+    return leaf_family_p1<T, D0, SV, kLeafVec, MODE>;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+// loop launches (kernels_leaf_loop.h): the kernel and the dynamic LDS its evidence rings need
+template <typename T>
+struct LeafLoopKernel {
+  LeafFamilyFn<T> fn = nullptr;
+  size_t lds_bytes = 0;
+};
+
+template <typename T, int D0, int OUT, int STATE>
+inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s) {
+  constexpr bool kFromCaller = STATE == kLoopIngest;
+  switch (s) {
+#define X(SV)                                                                                       \
+  case SV:                                                                                          \
+    if constexpr (SV == 2 || (STATE != kLoopIngest && STATE != kLoopIngestStates))                  \
+      return {leaf_loop_p1<T, D0, SV, OUT, STATE>,                                                  \
+              (size_t)kWavesPerBlock * LeafRing<T, SV, kFromCaller>::kWaveBytes};                   \
+    break;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return {};
+}
+
+template <typename T, int OUT, int STATE>
+inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_loop_for_s<T, DV, OUT, STATE>(s);
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return {};
+}
+
+// reduce-mode launches of two-state leaves with four observations per lane
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_lookup_pairs4(int32_t d0) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_family_p1<T, DV, 2, 4, MODE>;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return leaf_family_for_s<T, DV, MODE>(s);
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+
+// w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
+template <typename T>
+int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena, const T* cpts,
+                       int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s, bool with_counts,
+                       bool next_is_last) {
+  const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+  const bool ingest_wanted = fresh && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next;
+  LeafFamilyFn<T> fn = nullptr;
+  size_t lds_bytes = 0;
+  const bool loop_p1 = mode == kLeafLoop && !w2;
+  int32_t loop_out = kLoopLight;
+  if (loop_p1) {
+    // one-parent loop launch: the launch before a full / reduce launch leaves one z per family,
+    // any earlier one the chunk products of the z
+    loop_out = next_is_last ? kLoopLast : kLoopLight;
+    int32_t from = fresh ? kLoopFresh : (first_iteration ? kLoopFromArrays : kLoopChunk);
+    if (ingest_wanted) {
+      if (loop_out != kLoopLight) return -1;  // callers ask for ingestion only with a loop launch to spare
+      from = fast_state(p)->ingest_states ? kLoopIngestStates : kLoopIngest;
+    }
+    if (from == kLoopChunk && fam.z_form != kZPerChunk) return -1;
+    LeafLoopKernel<T> k;
+    switch (loop_out * 8 + from) {
+#define X(OUT, FROM)                                                      \
+  case OUT * 8 + FROM:                                                    \
+    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1]);             \
+    break;
+      X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
+      X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates)
+      X(kLoopLast, kLoopChunk) X(kLoopLast, kLoopFresh) X(kLoopLast, kLoopFromArrays)
+#undef X
+    }
+    fn = k.fn;
+    lds_bytes = k.lds_bytes;
+    if (fn && lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return -1;
+  } else if (w2) {
+    if (ingest_wanted) return -1;
+    switch (mode + 3 * state) {
+#define X(M) \
+  case M:    \
+    fn = leaf_family_p2<T, 2, 2, 2, kLeafVec, M>; \
+    break;
+      X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+    }
+  } else {
+    if (ingest_wanted) return -1;  // the evidence would never reach the arena
+    if (state == kLeafSteady && fam.z_form != kZPerFamily) return -1;
+    switch (mode + 3 * state) {
+#define X(M) \
+  case M:    \
+    fn = leaf_family_lookup<T, M>(g.dims[0], g.dims[1]); \
+    break;
+      X(1) X(2) X(4) X(5) X(7) X(8)
+#undef X
+    }
+  }
+  // Reduce mode writes no partial products, so it is free to cut the families differently: with
+  // four observations per lane (one wave per tile and chunk) the count sums cross the lanes half
+  // as often per observation.
+  bool wide4 = false;
+  int32_t chunks_r = 0;
+  if constexpr (std::is_same<T, float>::value) {
+    if (mode == kLeafReduce && !w2 && g.dims[1] == 2 && p.tile == 256 && !env_reduce_v2()) {
+      LeafFamilyFn<T> fn4 = nullptr;
+      switch (state) {
+        case kLeafSteady: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafSteady>(g.dims[0]); break;
+        case kLeafFresh: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFresh>(g.dims[0]); break;
+        case kLeafFromArrays: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFromArrays>(g.dims[0]); break;
+      }
+      if (fn4) {
+        // 140 VGPRs, three waves per SIMD: one round of resident waves (3 x 1024) per launch
+        int64_t want = std::max<int64_t>(1, 3072 / p.ntiles);
+        if (env_reduce_chunks() > 0) want = env_reduce_chunks();
+        chunks_r = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, fam.ll_rows_cap), (int64_t)g.nodes.size()));
+        fn = fn4;
+        wide4 = true;
+      }
+    }
+  }
+  if (!fn) return -1;
+  if (w2 && (w2->chunks != fam.chunks || w.chunks != fam.chunks || w2->chunk_len != fam.chunk_len)) return -1;
+  LeafFamilyArgs<T> a;
+  a.f_in = g.d_in;
+  a.f_out = g.d_out;
+  a.cpt_off = g.d_cpt;
+  a.obs_off = fam.d_obs_off;
+  a.c_off = fam.d_c_off;
+  a.K = (int32_t)g.nodes.size();
+  a.chunks = fam.chunks;
+  a.chunk_len = fam.chunk_len;
+  a.chunk_base = fam.chunk_base;
+  a.part_mant = w.part_mant;
+  a.part_exp = w.part_exp;
+  a.scaled = w.scaled;
+  a.npad = p.npad;
+  a.ntiles = p.ntiles;
+  a.N = p.N;
+  a.z_state = static_cast<T*>(fam.z_state);
+  a.zc_mant = fam.zc_mant;
+  a.zc_exp = fam.zc_exp;
+  a.em_partial = with_counts ? static_cast<T*>(fam.em_partial) : nullptr;
+  a.slots = fam.slots;
+  a.ll_part = fam.ll_part;
+  a.part_mant2 = w2 ? w2->part_mant : nullptr;
+  a.part_exp2 = w2 ? w2->part_exp : nullptr;
+  a.scaled2 = w2 ? w2->scaled : nullptr;
+  a.m_state = static_cast<T*>(fam.m_state);
+  a.src = fam.d_src;
+  a.on_value = (T)fast_state(p)->ingest_on;
+  a.off_value = (T)fast_state(p)->ingest_off;
+  int64_t waves = (int64_t)fam.chunks * p.ntiles * leaf_parts(p);
+  if (wide4) {
+    const int32_t K = (int32_t)g.nodes.size();
+    a.chunk_len = (K + chunks_r - 1) / chunks_r;
+    a.chunks = (K + a.chunk_len - 1) / a.chunk_len;
+    a.slots = (int32_t)p.ntiles;
+    waves = (int64_t)a.chunks * p.ntiles;
+  }
+  launch(fn, dim3(wave_blocks(waves)), dim3(256), lds_bytes, s, arena, cpts, a);
+  if (!launch_ok()) return -1;
+  if (loop_p1) fam.z_form = loop_out == kLoopLast ? kZPerFamily : kZPerChunk;
+  if (mode == kLeafReduce) {
+    fam.ll_rows = a.chunks;
+    fam.slots_used = a.slots;
+    fam.pending = true;
+    fam.pending_fresh = fresh;
+    fam.pending_first = first_iteration;
+    fam.em_ready = with_counts;
+  } else {
+    fam.pending = false;
+    fam.em_ready = false;
+    w.partials_valid = true;
+    if (w2) w2->partials_valid = true;
+  }
+  return 1;
+}
+
+}  // namespace bn

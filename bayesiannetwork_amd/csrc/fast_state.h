@@ -1,0 +1,120 @@
+// State the specialised path keeps per plan (which groups run on the wide-node / leaf-family
+// kernels, their scratch and loop state); shared by the translation units that launch them.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace bn {
+
+constexpr int32_t kMaxUncovered = 8;
+// observations per lane in the leaf-family kernel: 4 leaves one wave per SIMD, 1 doubles the
+// per-family instruction overhead (both measured slower on the 784-leaf model)
+constexpr int32_t kLeafVec = 2;
+// waves a leaf-family launch needs per tile (a wave covers 64 * kLeafVec observations)
+inline int32_t leaf_parts(const Plan& p) { return p.tile / (64 * kLeafVec); }
+
+struct WideNode {
+  int32_t node = -1, vgroup = -1, vpos = -1;
+  int32_t S = 0, I = 0;
+  int32_t fused_fgroup = -1;  // first factor group whose leaf-family kernel maintains partials of this node, or -1
+  std::vector<int32_t> fused_fgroups;  // all of them, in the order their families appear in `covered`
+  int32_t chunks = 0, chunk_len = 0;
+  std::vector<int32_t> covered, uncovered;
+  int32_t* d_covered = nullptr;
+  int32_t* d_uncovered = nullptr;
+  int32_t* d_chunk_first = nullptr;  // [chunks + 1] chunk boundaries in `covered`
+  double* part_mant = nullptr;
+  int32_t* part_exp = nullptr;
+  double* scaled = nullptr;
+  bool partials_valid = false;
+};
+
+struct FusedFamily {
+  int32_t wide_index = -1;
+  int32_t wide_index2 = -1;     // second wide parent of two-parent families, else -1
+  int32_t chunk_base = 0, chunks = 0, chunk_len = 0;  // this group's range of the parent's chunk partials
+  void* m_state = nullptr;      // [K][D0 + D1][npad] of the plan's element type: two-parent loop state (previous messages to the parents)
+  int64_t* d_obs_off = nullptr;
+  int64_t* d_c_off = nullptr;
+  std::vector<int32_t> ev_index;   // [K] position of each leaf in the evidence order, -1 = not observed
+  const void** d_src = nullptr;    // [K] evidence source of each leaf for an ingesting launch
+  std::vector<const void*> src_on_device;  // what d_src holds
+  void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
+  // chunk products of the normalisers: the state between two loop launches of a one-parent group
+  double* zc_mant = nullptr;    // [chunks][npad]
+  int32_t* zc_exp = nullptr;    // [chunks][npad]
+  // which of the two the last loop launch wrote: kZPerFamily (z_state; what full / reduce launches
+  // read), kZPerChunk (zc_*; what the next loop launch reads), kZNone after a reset
+  int32_t z_form = 0;
+  void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
+  int32_t slots = 0;
+  double* ll_part = nullptr;    // [chunks][npad], written by the reduce-mode kernel
+  int32_t ll_rows = 0;          // rows the last reduce-mode launch wrote
+  int32_t ll_rows_cap = 0;      // rows allocated
+  int32_t slots_used = 0;       // per-wave sum slots the last reduce-mode launch wrote
+  // the last iteration ran in reduce mode: stored messages are one iteration behind until
+  // complete_pending_fast re-runs it in full mode with these flags
+  bool pending = false;
+  int32_t pending_fresh = 0, pending_first = 0;
+  bool em_ready = false;  // em_partial holds the counts of the current state
+};
+
+constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2;
+
+struct FastState {
+  // normaliser arrays of the nodes no fused family serves (the rest of a log-likelihood sum
+  // comes from the families' ll_part rows when their last iteration ran in reduce mode)
+  int64_t* d_ll_offs = nullptr;
+  int64_t n_ll_offs = 0;
+  // CPT entries of the nodes no fused family serves (the only ones the generic EM sums have to
+  // finalise when every fused group delivers its own counts)
+  int32_t* d_unfused_entries = nullptr;
+  int32_t n_unfused_entries = 0;
+  std::vector<WideNode> wide;
+  std::map<int32_t, int32_t> wide_of_node;   // node id -> index in `wide`
+  std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
+  std::vector<char> vgroup_skip;              // variable groups whose every node a fused kernel serves
+  std::vector<char> vgroup_wide;              // variable groups served by the wide-node path
+  // parentless factor groups whose output (the prior, broadcast over observations) is already in
+  // place: it only changes with the CPTs
+  std::vector<char> root_written;
+  // Every observed node is a two-state leaf of a one-parent fused family: the first iteration
+  // after a reset can read the evidence from the caller's arrays and write the arena copy itself.
+  bool ingest_ok = false;
+  bool ingest_next = false;  // the coming first iteration does so (evidence pointers are on the device)
+  bool ingest_states = false;  // ... from uint8 states (bn_enter_evidence_states' format) instead of float arrays
+  bool ingest_all_observed = false;  // every leaf of every ingesting group is observed (the uint8 route needs it)
+  double ingest_on = 1.0, ingest_off = 0.0;
+};
+
+// The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
+inline FastState* fast_state(const Plan& p) { return static_cast<FastState*>(p.fast); }
+
+// Tuning overrides read once per process (benchmark experiments only):
+//   BN_WIDE_CHUNKS=n    chunks per wide node        BN_REDUCE_CHUNKS=n  chunks of a reduce-mode launch
+//   BN_REDUCE_V2=1      reduce-mode launches with two observations per lane, like the other modes
+inline int32_t env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+inline int32_t env_wide_chunks() {
+  static const int32_t v = env_int("BN_WIDE_CHUNKS");
+  return v;
+}
+inline int32_t env_reduce_chunks() {
+  static const int32_t v = env_int("BN_REDUCE_CHUNKS");
+  return v;
+}
+inline bool env_reduce_v2() {
+  static const bool v = getenv("BN_REDUCE_V2") != nullptr;
+  return v;
+}
+
+}  // namespace bn

@@ -307,7 +307,7 @@ constexpr int32_t kAddressBatch = 448;  // 3.5 KiB of the 4 KiB kernel-argument 
 struct AddressBatch {
   const void* p[kAddressBatch];
 };
-__global__ void __launch_bounds__(256) store_addresses(AddressBatch batch, int32_t count, const void** __restrict__ dst) {
+static __global__ void __launch_bounds__(256) store_addresses(AddressBatch batch, int32_t count, const void** __restrict__ dst) {
   const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
   if (i < count) dst[i] = batch.p[i];
 }
@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256) normaliser_change_partial(const T* __rest
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(256) max_partials(const double* __restrict__ partial, int32_t count,
+static __global__ void __launch_bounds__(256) max_partials(const double* __restrict__ partial, int32_t count,
                                                    double* __restrict__ out) {
   __shared__ double red[256];
   double worst = 0.0;
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) max_partials(const double* __restrict__ p
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-__global__ void __launch_bounds__(256) sum_partials(const double* __restrict__ partial, int32_t count,
+static __global__ void __launch_bounds__(256) sum_partials(const double* __restrict__ partial, int32_t count,
                                                    double scale, double* __restrict__ out) {
   __shared__ double red[256];
   double acc = 0.0;

@@ -354,10 +354,10 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
         for (int32_t i = 0; i < D0; ++i)
 #pragma unroll
           for (int32_t j = 0; j < S; ++j) {
-            const fv<T, V> prod = r[i] * o[j];
-            T x = prod[0];
+            // a chain of fused multiply-adds: half the issue slots of packed products plus adds
+            T x = r[i][0] * o[j][0];
 #pragma unroll
-            for (int32_t v = 1; v < V; ++v) x += prod[v];
+            for (int32_t v = 1; v < V; ++v) x = fma_t(r[i][v], o[j][v], x);
             per_lane[i * S + j] = x;
           }
         WaveSums<T, D0 * S> sums;

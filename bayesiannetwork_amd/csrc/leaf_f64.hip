@@ -1,0 +1,8 @@
+// The leaf-family kernels of double plans, in a translation unit of their own (they are most of the
+// library's device code; the two element types compile side by side).
+#include "dispatch_leaf.h"
+
+namespace bn {
+template int launch_leaf_family<double>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, double*, const double*, int32_t,
+                                     int32_t, int32_t, hipStream_t, bool, bool);
+}  // namespace bn
