@@ -492,7 +492,7 @@ def config_c5_mini():
         cpts[name] = rand_cpt(gen, (S, S))
         obs.append(name)
     gen = torch.Generator().manual_seed(1)
-    N = 48
+    N = 256
     evidence = {o: one_hot_rows(gen, N, S, gamma=1 - 1e-6) for o in obs}
     want = dict(single="all", family=[], counts=True, messages=False)
     emit(dict(name="c5_mini", nodes=nodes, observed=obs, N=N), cpts, evidence, want)
@@ -621,8 +621,8 @@ def main():
     mnist_like(16, False, 32, "c3a_mini16", ALL)
     mnist_like(16, True, 32, "c3b_mini16", ALL)
     slim = dict(single=["Q", "F1", "F2", "Y0", "Y391", "Y783"], family=["Q", "Y0", "Y783"], counts=True, messages=False)
-    mnist_like(784, False, 24, "c3a_784", slim)
-    mnist_like(784, True, 24, "c3b_784", slim)
+    mnist_like(784, False, 64, "c3a_784", slim)
+    mnist_like(784, True, 64, "c3b_784", slim)
     config_c5_mini()
     config_em()
 

@@ -1,0 +1,304 @@
+"""GPU parity on the benchmarked models at sizes the golden fixtures do not reach, against the CPU
+oracle run in float64 on the same inputs (the oracle is pinned to the reference by the fixtures,
+tests/test_oracle_golden.py; nothing here has a reference-generated answer of its own):
+
+* the 784-leaf models (one hidden node / the loopy two-feature form) at 1 025 observations of
+  DISTINCT rows, soft and hard mixed: five observation tiles, every chunk of families, a ragged last
+  tile; through the query route, the one-call statistics route and compact hard evidence;
+* the deep tree of 64-state nodes at its benchmarked depth (6 levels, 95 nodes, 24 iterations).
+
+Tolerance (float32): 1e-5 relative + 1e-7 of the tensor's scale on trees; a node's normaliser
+c = log sum_s prod_i in_i[s] gets 2e-6 + 2e-7 per input message on top (every leaf family works from
+the wide parent's product rounded to float32 once, up to 6e-8 of each state, and that shared
+rounding moves all 784 messages to the parent the same way instead of averaging out: 1.2e-4 seen on
+the 785-input node with soft evidence, where the reference's own float32 run is off by 4e-4; the
+log-likelihood, in which these shifts cancel against the leaves' normalisers, stays within 1e-5
+relative).  The loopy model's ten iterations feed rounding back into themselves, so two correct
+float32 implementations drift apart: there the yardstick is the oracle run in float32 as well (the
+reference's own float32 arithmetic).  Ten iterations amplify the rounding of a few ill-conditioned
+observations by four orders of magnitude (errors up to 3e-3 on single rows in either float32 run,
+tools/diag_c3b.py), so on that model 99 % of the entries of a tensor must be within ten times the
+bound above, and the largest error within ten times the largest error of the float32 oracle.
+float64: 1e-9 relative.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_cpt(gen, shape):
+    p = torch.rand(shape, generator=gen, dtype=torch.float64) + 0.02
+    return p / p.sum(dim=-1, keepdim=True)
+
+
+def _leaf_model(kind, dtype, device):
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device=device, dtype=dtype)
+    gen = torch.Generator().manual_seed(11)
+
+    def cpt(shape):
+        return _rand_cpt(gen, shape).to(ts.dtype).to(ts.device)
+
+    q = Node(cpt((10,)), name="Q")
+    builder = BayesianNetworkBuilder().add_node(q)
+    ys = []
+    if kind == "c3b":
+        f1, f2 = Node(cpt((10, 2)), name="F1"), Node(cpt((10, 2)), name="F2")
+        builder.add_node(f1, parents=q).add_node(f2, parents=q)
+        for i in range(784):
+            ys.append(Node(cpt((2, 2, 2)), name=f"Y{i}"))
+            builder.add_node(ys[-1], parents=[f1, f2])
+    else:
+        for i in range(784):
+            ys.append(Node(cpt((10, 2)), name=f"Y{i}"))
+            builder.add_node(ys[-1], parents=q)
+    return ts, builder.build(), ys
+
+
+def _mixed_evidence(n, count, seed, torch_dtype):
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(count):
+        soft = torch.rand((n, 2), generator=gen, dtype=torch.float64) + 1e-3
+        soft = soft / soft.sum(-1, keepdim=True)
+        x = (torch.rand((n,), generator=gen) < 0.3).double() * 0.999999 + 5e-7
+        hard = torch.stack([1 - x, x], dim=1)
+        pick = (torch.rand((n, 1), generator=gen) < 0.6).double()
+        out.append((pick * hard + (1 - pick) * soft).to(torch_dtype))
+    return out
+
+
+def _check(got, want, what, f32, slack=1.0, extra_atol=0.0, yardstick=None):
+    """yardstick: the same quantity from the float32 run of the oracle (loopy models only)."""
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().double().numpy()
+    assert np.isfinite(got).all(), what
+    if f32:
+        scale = float(np.max(np.abs(want))) if want.size else 1.0
+        bound = slack * (1e-5 * np.abs(want) + 1e-7 * scale + extra_atol)
+    else:
+        bound = slack * (1e-9 * np.abs(want) + 1e-12)
+    ratio = np.abs(got - want) / bound
+    worst = float(np.max(ratio))
+    if f32 and yardstick is not None:
+        theirs = float(np.max(np.abs(yardstick.detach().double().numpy() - want) / bound))
+        if ratio.size >= 1000:  # per-observation tensors; sums over observations only have the second rule
+            typical = float(np.quantile(ratio, 0.99))
+            assert typical <= 1.0, f"{what}: 99 % of the entries are within {typical:.2f}x the bound"
+        assert worst <= max(1.0, 10.0 * theirs), f"{what}: {worst:.2f}x the bound (float32 oracle: {theirs:.2f}x)"
+        return worst
+    assert worst <= 1.0, f"{what}: {worst:.2f}x the bound"
+    return worst
+
+
+def _oracle_for(kind, network_dev, ys_dev, dtype, n, iterations, loops, evidence, oracle_dtype=torch.float64):
+    from oracle.spa_oracle import SpaOracle
+
+    _, network64, ys64 = _leaf_model(kind, "float64", "cpu")
+    for node64, node in zip(network64.nodes, network_dev.nodes):  # same rounded CPT values as the device network
+        node64.cpt = node.cpt.detach().cpu().double()
+    oracle = SpaOracle(network64, ys64, n, dtype=oracle_dtype, num_iterations=iterations, allow_loops=loops)
+    oracle.enter_evidence([e.to(oracle_dtype) for e in evidence])
+    return oracle
+
+
+class _NoYardstick:
+    """Stands in for the float32 oracle where none is needed: every query answers None."""
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b"])
+def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    n = 1025
+    loops, iterations = (True, 10) if kind == "c3b" else (False, None)
+    f32 = dtype == "float32"
+    slack = 10.0 if loops else 1.0
+    ts, network, ys = _leaf_model(kind, dtype, "cuda")
+    evidence = _mixed_evidence(n, len(ys), 5, ts.dtype)
+    oracle = _oracle_for(kind, network, ys, dtype, n, iterations, loops, evidence)
+    o32 = (_oracle_for(kind, network, ys, dtype, n, iterations, loops, evidence, torch.float32)
+           if loops and f32 else _NoYardstick())
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations, allow_loops=loops)
+    nodes = list(network.nodes)
+    picks = sorted({0, 1, 2, 3, len(nodes) // 2, len(nodes) - 1})
+
+    def family_sum(o, j):
+        fam = o.infer_family(j)
+        return None if fam is None else fam.sum(dim=0)
+
+    def ll_ok(got):
+        limit = slack * (1e-5 if f32 else 1e-9) * abs(want_ll)
+        if loops and f32:
+            limit = max(limit, 10.0 * abs(o32.log_likelihood(False) - want_ll))
+        return abs(got - want_ll) <= limit
+
+    # query route: bn_iterate, then marginals / normalisers / log-likelihood / counts
+    machine = HipSpaInferenceMachine(settings, network, ys, n)
+    machine.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
+    for j in picks:
+        _check(machine.infer_single_nodes([nodes[j]])[0], oracle.infer_single(j), f"single {nodes[j].name}", f32, slack,
+               yardstick=o32.infer_single(j))
+        _check(machine.infer_nodes_with_parents([nodes[j]])[0], oracle.infer_family(j), f"family {nodes[j].name}", f32, slack,
+               yardstick=o32.infer_family(j))
+    observed = set(ys)
+    for j in picks:
+        inputs = len(list(network.children_of(nodes[j]))) + 1 + (nodes[j] in observed)
+        g, k = oracle.v_of[j]
+        c32 = None
+        if loops and f32:
+            o32.log_likelihood(False)  # makes the float32 oracle iterate
+            c32 = o32.vgroups[g]["c"][k]
+        _check(machine.local_log_likelihoods(nodes[j]), oracle.vgroups[g]["c"][k], f"c {nodes[j].name}", f32, slack,
+               extra_atol=2e-6 + 2e-7 * inputs, yardstick=c32)
+    want_ll = oracle.log_likelihood(False)
+    assert ll_ok(machine.log_likelihood())
+    want_counts = [oracle.infer_family(j).sum(dim=0) for j in range(len(nodes))]
+    counts32 = [family_sum(o32, j) for j in range(len(nodes))]
+    for j, got in enumerate(machine.split_counts(machine.expected_count_sums())):
+        _check(got, want_counts[j], f"counts {nodes[j].name}", f32, slack, yardstick=counts32[j])
+
+    # one-call statistics route (evidence read by the first iteration where the model allows it;
+    # 1 025 is odd, 1 026 below is even: both sides of that condition)
+    one_call = HipSpaInferenceMachine(settings, network, ys, n)
+    ll, flat = one_call.em_statistics(Evidence([e.cuda() for e in evidence], ts))
+    assert ll_ok(ll.item())
+    for j, got in enumerate(one_call.split_counts(flat)):
+        _check(got, want_counts[j], f"counts via statistics {nodes[j].name}", f32, slack, yardstick=counts32[j])
+    # and the queries made afterwards see the completed last iteration
+    _check(one_call.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), "single Q after statistics", f32, slack,
+           yardstick=o32.infer_single(0))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b"])
+def test_784_leaf_models_statistics_from_float_and_hard_evidence(kind, dtype):
+    """An even number of observations, hard rows only: the float route ingests the caller's arrays in
+    its first iteration, the uint8 route the state bytes; both must equal the oracle on the tensors
+    the hard evidence stands for."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    n = 1026
+    loops, iterations = (True, 10) if kind == "c3b" else (False, None)
+    f32 = dtype == "float32"
+    slack = 10.0 if loops else 1.0
+    ts, network, ys = _leaf_model(kind, dtype, "cuda")
+    gen = torch.Generator().manual_seed(9)
+    states = (torch.rand((len(ys), n), generator=gen) < 0.25).to(torch.uint8)
+    hard = HardEvidence(states.cuda(), [2] * len(ys), ts, on_value=0.999999 + 5e-7, off_value=5e-7)
+    tensors = [t.clone() for t in hard.data]
+    oracle = _oracle_for(kind, network, ys, dtype, n, iterations, loops, [t.cpu() for t in tensors])
+    o32 = (_oracle_for(kind, network, ys, dtype, n, iterations, loops, [t.cpu() for t in tensors], torch.float32)
+           if loops and f32 else _NoYardstick())
+    want_ll = oracle.log_likelihood(False)
+    nodes = list(network.nodes)
+    want_counts = [oracle.infer_family(j).sum(dim=0) for j in range(len(nodes))]
+    counts32 = [None if o32.infer_family(j) is None else o32.infer_family(j).sum(dim=0) for j in range(len(nodes))]
+    ll_limit = slack * (1e-5 if f32 else 1e-9) * abs(want_ll)
+    if loops and f32:
+        ll_limit = max(ll_limit, 10.0 * abs(o32.log_likelihood(False) - want_ll))
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations, allow_loops=loops)
+    for route, evidence in (("float", Evidence(tensors, ts)), ("uint8", hard)):
+        machine = HipSpaInferenceMachine(settings, network, ys, n)
+        ll, flat = machine.em_statistics(evidence)
+        assert abs(ll.item() - want_ll) <= ll_limit, route
+        for j, got in enumerate(machine.split_counts(flat)):
+            _check(got, want_counts[j], f"{route}: counts {nodes[j].name}", f32, slack, yardstick=counts32[j])
+        for node, want in zip(ys[:3], tensors[:3]):
+            assert torch.equal(machine.observation(node), want), f"{route}: observation slot of {node.name}"
+        _check(machine.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), f"{route}: single Q", f32, slack,
+               yardstick=o32.infer_single(0))
+
+
+def _deep_tree(dtype, device, depth=6, states=64):
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device=device, dtype=dtype)
+    gen = torch.Generator().manual_seed(3)
+
+    def cpt(shape):
+        return _rand_cpt(gen, shape).to(ts.dtype).to(ts.device)
+
+    root = Node(cpt((states,)), name="H0")
+    builder = BayesianNetworkBuilder().add_node(root)
+    frontier, count = [root], 1
+    for _ in range(depth - 1):
+        nxt = []
+        for parent in frontier:
+            for _ in range(2):
+                node = Node(cpt((states, states)), name=f"H{count}")
+                count += 1
+                builder.add_node(node, parents=parent)
+                nxt.append(node)
+        frontier = nxt
+    leaves = []
+    for i, parent in enumerate(frontier):
+        leaves.append(Node(cpt((states, states)), name=f"Y{i}"))
+        builder.add_node(leaves[-1], parents=parent)
+    return ts, builder.build(), leaves
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_deep_tree_of_64_state_nodes_at_benchmark_depth(dtype):
+    """63 hidden + 32 observed 64-state nodes, 24 iterations (the factor-graph diameter): the dense
+    matrix-core factor pass, the split-state variable pass and the count GEMM on the shape that is
+    benchmarked, 300 observations (two tiles, the second ragged)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from oracle.spa_oracle import SpaOracle
+
+    n = 300
+    f32 = dtype == "float32"
+    ts, network, leaves = _deep_tree(dtype, "cuda")
+    gen = torch.Generator().manual_seed(4)
+    evidence = []
+    for _ in leaves:
+        idx = torch.randint(0, 64, (n,), generator=gen)
+        hard = torch.nn.functional.one_hot(idx, 64).double() * (1 - 1e-6) + 5e-7
+        soft = torch.rand((n, 64), generator=gen, dtype=torch.float64) + 1e-3
+        pick = (torch.rand((n, 1), generator=gen) < 0.5).double()
+        evidence.append((pick * hard + (1 - pick) * soft / soft.sum(-1, keepdim=True)).to(ts.dtype))
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, leaves, n)
+    assert machine.num_iterations == 24
+    machine.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
+
+    _, network64, leaves64 = _deep_tree("float64", "cpu")
+    for node64, node in zip(network64.nodes, network.nodes):
+        node64.cpt = node.cpt.detach().cpu().double()
+    oracle = SpaOracle(network64, leaves64, n, dtype=torch.float64)
+    assert oracle.num_iterations == 24
+    oracle.enter_evidence([e.double() for e in evidence])
+
+    nodes = list(network.nodes)
+    index = {node: j for j, node in enumerate(nodes)}
+    want_ll = oracle.log_likelihood(False)
+    assert abs(machine.log_likelihood() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
+    by_name = {node.name: node for node in nodes}
+    for name in ("H0", "H5", "H40", "Y0", "Y31"):  # root, inner nodes, first and last leaf
+        j = index[by_name[name]]
+        _check(machine.infer_single_nodes([nodes[j]])[0], oracle.infer_single(j), f"single {name}", f32)
+    for name in ("H5", "Y31"):
+        j = index[by_name[name]]
+        _check(machine.infer_nodes_with_parents([nodes[j]])[0], oracle.infer_family(j), f"family {name}", f32)
+    counts = machine.split_counts(machine.expected_count_sums())
+    second = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, leaves, n)
+    ll2, flat2 = second.em_statistics(Evidence([e.cuda() for e in evidence], ts))
+    assert abs(ll2.item() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
+    counts2 = second.split_counts(flat2)
+    for name in ("H0", "H1", "H5", "H40", "Y0", "Y31"):
+        j = index[by_name[name]]
+        want = oracle.infer_family(j).sum(dim=0)
+        _check(counts[j], want, f"counts {name}", f32)
+        _check(counts2[j], want, f"counts via statistics {name}", f32)

@@ -4,9 +4,12 @@ fixtures (reference outputs) on identical inputs.
 Tolerances
   float64: rtol 1e-10 against the reference's float64 output;
   float32: rtol 1e-5 (+ atol 1e-7 * max|expected| for near-zero entries) against the
-           reference run in float64 on the same float32 inputs ("truth"); where the
-           reference's own float32 output misses that bound (it does on the 784-leaf
-           models, by up to 15x), being at least as close to the truth as the reference;
+           reference run in float64 on the same float32 inputs ("truth").  Tree-shaped
+           networks must meet that bound outright, including the 784-leaf model where the
+           reference's own float32 output misses it by up to 15x.  Loopy networks feed
+           rounding errors back into the iteration: 4x the bound there, or twice the distance
+           of the reference's own float32 run from the truth where that misses it too (two
+           float32 runs round independently, so their errors agree in size, not in value);
            a normaliser c = log sum_s prod_i in_i[s] gets 2e-6 + 1e-7 per input message on
            top: every float32 input carries a rounding error of up to 6e-8 of its value,
            which moves c by that much in absolute terms however close to zero c itself is
@@ -24,6 +27,21 @@ import torch
 from conftest import Fixture, em_fixture_names, fixture_names
 
 pytestmark = pytest.mark.gpu
+
+# achieved error / bound per fixture and kind of quantity, ours and the reference's own float32
+# run; written to gpurun_out/parity_margins.json when the module's tests are done
+MARGINS = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_margins():
+    yield
+    import os
+
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if MARGINS and os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_margins.json"), "w") as f:
+            json.dump(MARGINS, f, indent=1, sort_keys=True)
 
 
 def _machine(fx, average=False):
@@ -69,12 +87,17 @@ def _close(got, fx, key, f64_rtol=1e-10, extra_atol=0.0):
     ours = float(np.max(np.abs(got - truth) / bound)) if truth.size else 0.0
     theirs = float(np.max(np.abs(ref32 - truth) / bound)) if truth.size else 0.0
     assert np.isfinite(got).all(), key
-    assert ours <= max(1.0, theirs), (
+    kind = key.split("/")[0]
+    entry = MARGINS.setdefault(fx.name, {}).setdefault(kind, {"ours_over_bound": 0.0, "reference_f32_over_bound": 0.0})
+    entry["ours_over_bound"] = max(entry["ours_over_bound"], ours)
+    entry["reference_f32_over_bound"] = max(entry["reference_f32_over_bound"], theirs)
+    limit = max(1.0, 2.0 * theirs) if fx.meta["allow_loops"] else 1.0
+    assert ours <= limit, (
         f"{key}: error vs float64 truth is {ours:.2f}x the bound "
         f"(the reference's own float32 run: {theirs:.2f}x)"
     )
     # and against the reference's float32 output itself, within the two errors combined
-    assert float(np.max(np.abs(got - ref32) / bound)) <= max(1.0, theirs) + theirs, key + " vs float32 reference"
+    assert float(np.max(np.abs(got - ref32) / bound)) <= limit + theirs, key + " vs float32 reference"
 
 
 @pytest.mark.parametrize("name", fixture_names())
