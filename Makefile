@@ -6,7 +6,7 @@ OUT   := bayesiannetwork_amd/libbn_hip.so
 OBJ   := build
 HDRS  := $(wildcard $(SRC)/*.h) include/bn_hip.h
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
-OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/plan.o
+OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/sampler.o $(OBJ)/plan.o
 
 all: $(OUT)
 

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime the library must share)
 
@@ -92,6 +92,16 @@ def _declare(lib):
     lib.bn_exact_log_likelihood.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     lib.bn_exact_marginal.restype = c_int
     lib.bn_exact_marginal.argtypes = [c_void_p, i32p, c_int32, c_void_p, c_void_p]
+    lib.bn_sampler_create.restype = c_int
+    lib.bn_sampler_create.argtypes = [c_int, c_int32, i32p, i32p, i32p, POINTER(c_void_p)]
+    lib.bn_sampler_destroy.restype = c_int
+    lib.bn_sampler_destroy.argtypes = [c_void_p]
+    lib.bn_sampler_cpt_elements.restype = c_int64
+    lib.bn_sampler_cpt_elements.argtypes = [c_void_p]
+    lib.bn_sampler_workspace_bytes.restype = c_int64
+    lib.bn_sampler_workspace_bytes.argtypes = [c_void_p, i32p, c_int32, c_int64]
+    lib.bn_sampler_sample.restype = c_int
+    lib.bn_sampler_sample.argtypes = [c_void_p, c_void_p, i32p, c_int32, c_int64, c_uint64, c_void_p, c_void_p, c_void_p]
     lib.bn_profile_enable.restype = c_int
     lib.bn_profile_enable.argtypes = [c_int32]
     lib.bn_profile_only.restype = c_int
@@ -109,6 +119,8 @@ EXPORTS = (
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_static", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
     "bn_exact_log_likelihood", "bn_exact_marginal",
+    "bn_sampler_create", "bn_sampler_destroy", "bn_sampler_cpt_elements", "bn_sampler_workspace_bytes",
+    "bn_sampler_sample",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only", "bn_profile_stride",
 )
 

@@ -1,4 +1,5 @@
 from .abstractions import IBayesianNetworkSampler
 from .batched_sampler import BatchedBayesianNetworkSampler
+from .hip_sampler import HipBayesianNetworkSampler
 
-__all__ = ["IBayesianNetworkSampler", "BatchedBayesianNetworkSampler"]
+__all__ = ["IBayesianNetworkSampler", "BatchedBayesianNetworkSampler", "HipBayesianNetworkSampler"]

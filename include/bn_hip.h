@@ -307,6 +307,33 @@ int bn_exact_marginal(bn_exact* machine, const int32_t* nodes, int32_t num_query
                       void* stream);
 
 /*
+ * Ancestral sampling on the device.  Replaces TorchBayesianNetworkSampler
+ * (samplers/torch_sampler.py:10-60), which draws one joint sample per Python loop iteration with one
+ * torch.multinomial call per node: here one thread draws one joint sample, walking the requested
+ * nodes and their ancestors parents-first (the reference's recursion order, :43-52) and inverting
+ * the selected CPT row's cumulative distribution at a counter-based uniform number (Philox-4x32-10:
+ * a draw is a function of seed, sample index and node only).  Topology arguments as
+ * bn_plan_create; bound to the current HIP device.
+ */
+typedef struct bn_sampler bn_sampler;
+int bn_sampler_create(int dtype, int32_t num_nodes, const int32_t* num_states, const int32_t* parent_offsets,
+                      const int32_t* parent_indices, bn_sampler** out_sampler);
+int bn_sampler_destroy(bn_sampler* sampler);
+/* Element count of the flat CPT buffer the sampler reads (all CPTs in node order). */
+int64_t bn_sampler_cpt_elements(const bn_sampler* sampler);
+/* Bytes of device workspace bn_sampler_sample needs for this request (drawn states of the requested
+ * nodes and their ancestors, int32 [nodes walked][num_samples]); -1 on a bad argument. */
+int64_t bn_sampler_workspace_bytes(bn_sampler* sampler, const int32_t* nodes, int32_t num_requested, int64_t num_samples);
+/*
+ * out_dev[num_samples][num_requested] (int32, row-major, the reference's layout, :20-24) = jointly
+ * sampled states of nodes[0..num_requested), from the flat CPT buffer cpts_dev (sampler dtype).
+ * The call allocates nothing once the request's tables exist (they are rebuilt when `nodes`
+ * differs from the previous call's).
+ */
+int bn_sampler_sample(bn_sampler* sampler, const void* cpts_dev, const int32_t* nodes, int32_t num_requested,
+                      int64_t num_samples, uint64_t seed, void* workspace_dev, int32_t* out_dev, void* stream);
+
+/*
  * Per-kernel timing for benchmarks (process-wide switch): while enabled, every kernel any
  * plan launches carries a start/stop hipEvent pair attached to its dispatch (no marker
  * packets are put between kernels).
