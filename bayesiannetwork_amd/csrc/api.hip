@@ -216,6 +216,18 @@ void release(bn::Plan& p) {
     if (g.d_cpt) (void)hipFree(g.d_cpt);
   }
   if (p.arena) (void)hipFree(p.arena);
+  if (p.lazy_base) {
+    if (p.lazy_reserved) {
+      if (p.lazy_mapped) {
+        (void)hipMemUnmap(p.lazy_base, p.lazy_bytes);
+        (void)hipMemRelease(p.lazy_handle);
+      }
+      (void)hipMemAddressFree(p.lazy_base, p.lazy_bytes);
+    } else {
+      (void)hipFree(p.lazy_base);
+    }
+    p.lazy_base = nullptr;
+  }
   if (p.cpts) (void)hipFree(p.cpts);
   if (p.scratch) (void)hipFree(p.scratch);
   if (p.d_evidence_ptrs) (void)hipFree(p.d_evidence_ptrs);
@@ -226,6 +238,80 @@ void release(bn::Plan& p) {
   if (p.c_before) (void)hipFree(p.c_before);
   if (p.d_row_off) (void)hipFree(p.d_row_off);
   if (p.d_row_len) (void)hipFree(p.d_row_len);
+}
+
+hipMemAllocationProp lazy_memory_prop(int device) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  return prop;
+}
+
+// Address range for the message arrays of the leaf-family candidates (Plan::lazy_begin): reserved
+// without memory behind it where the runtime offers that, otherwise allocated straight away.
+// Afterwards every offset that pointed into the lazy part of the layout is relative to `arena`
+// again, so kernels keep addressing everything as arena + offset.
+int place_lazy_region(bn::Plan& p) {
+  if (p.lazy_elems <= 0) return BN_OK;
+  constexpr size_t kGranule = size_t(2) << 20;
+  p.lazy_bytes = (((size_t)p.lazy_elems * p.elem_size + kGranule - 1) / kGranule) * kGranule;
+  void* base = nullptr;
+  if (hipMemAddressReserve(&base, p.lazy_bytes, kGranule, nullptr, 0) == hipSuccess && base) {
+    p.lazy_reserved = true;
+    p.lazy_mapped = false;
+  } else {
+    (void)hipGetLastError();
+    BN_HIP_CHECK(hipMalloc(&base, p.lazy_bytes));
+    p.lazy_reserved = false;
+    p.lazy_mapped = true;
+    p.device_bytes += (int64_t)p.lazy_bytes;
+  }
+  p.lazy_base = base;
+  const int64_t byte_gap = static_cast<char*>(base) - static_cast<char*>(p.arena);
+  if (byte_gap % (int64_t)p.elem_size != 0) return fail(BN_ERR_HIP, "lazy region is not aligned to the element size");
+  const int64_t delta = byte_gap / (int64_t)p.elem_size - p.lazy_begin;
+  auto rebase = [&](int64_t& off) {
+    if (off >= p.lazy_begin) off += delta;
+  };
+  for (auto& e : p.edges) {
+    rebase(e.v2f);
+    rebase(e.f2v);
+  }
+  for (auto& g : p.vgroups) {
+    for (auto& off : g.in_off) rebase(off);
+    for (auto& off : g.out_off) rebase(off);
+  }
+  for (auto& g : p.fgroups) {
+    for (auto& off : g.in_off) rebase(off);
+    for (auto& off : g.out_off) rebase(off);
+  }
+  p.lazy_begin = -1;  // offsets are final
+  p.lazy_lo = byte_gap / (int64_t)p.elem_size;
+  p.lazy_hi = p.lazy_lo + p.lazy_elems;
+  return BN_OK;
+}
+
+// Backs the lazy region with memory (first call that reads or writes message arrays).
+int ensure_message_arrays(bn::Plan& p) {
+  if (p.lazy_elems <= 0 || p.lazy_mapped) return BN_OK;
+  hipMemAllocationProp prop = lazy_memory_prop(p.device);
+  BN_HIP_CHECK(hipMemCreate(&p.lazy_handle, p.lazy_bytes, &prop, 0));
+  hipError_t err = hipMemMap(p.lazy_base, p.lazy_bytes, 0, p.lazy_handle, 0);
+  if (err == hipSuccess) {
+    hipMemAccessDesc access = {};
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    err = hipMemSetAccess(p.lazy_base, p.lazy_bytes, &access, 1);
+    if (err != hipSuccess) (void)hipMemUnmap(p.lazy_base, p.lazy_bytes);
+  }
+  if (err != hipSuccess) {
+    (void)hipMemRelease(p.lazy_handle);
+    return fail(BN_ERR_HIP, std::string("mapping the message arrays: ") + hipGetErrorString(err));
+  }
+  p.lazy_mapped = true;
+  p.device_bytes += (int64_t)p.lazy_bytes;
+  return BN_OK;
 }
 
 int32_t em_chunks(const bn::Plan& p, int64_t active_nodes = -1) {
@@ -278,6 +364,8 @@ int reset_messages_t(bn::Plan& p, hipStream_t s) {
 // A leaf-family iteration that was only reduced (bn_em_statistics) is completed before anything
 // reads or changes messages, evidence or CPTs.
 int complete_pending(bn::Plan& p, hipStream_t s) {
+  if (bn::any_pending_fast(p))
+    if (int rc = ensure_message_arrays(p)) return rc;  // the re-run writes the message arrays
   if (bn::complete_pending_fast(p, s) < 0) return fail(BN_ERR_HIP, "launch of the leaf-family kernel failed");
   return BN_OK;
 }
@@ -302,6 +390,7 @@ int settle_observations(bn::Plan& p, hipStream_t s) {
 
 // Anything that reads message arrays directly needs them to hold real values.
 int materialize(bn::Plan& p, hipStream_t s) {
+  if (int rc = ensure_message_arrays(p)) return rc;
   if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_observations(p, s)) return rc;
   if (!p.fresh) return BN_OK;
@@ -316,6 +405,10 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
   T* arena = static_cast<T*>(p.arena);
   const T* cpts = static_cast<const T*>(p.cpts);
   const int32_t subs = p.tile / 64;
+  // message arrays are read when the iterations continue from stored messages, and written when the
+  // last one runs in full mode; a statistics call on fresh messages touches neither
+  if (iterations > 0 && (!p.fresh || reduce_last == 0))
+    if (int rc = ensure_message_arrays(p)) return rc;
   for (int32_t it = 0; it < iterations; ++it) {
     const int32_t fresh = p.fresh ? 1 : 0;
     for (auto& g : p.vgroups) {
@@ -326,6 +419,8 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         bn::variable_profile(p, (size_t)(&g - p.vgroups.data()), label, bytes);
         prof_begin(label, bytes, s);
       }
+      if (p.lazy_unmapped() && bn::variable_needs_arrays(p, (size_t)(&g - p.vgroups.data()), fresh))
+        if (int rc = ensure_message_arrays(p)) return rc;
       int rc = bn::launch_variable_fast<T>(p, g, arena, fresh, s);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised variable kernel failed");
       if (rc == 0) {
@@ -350,6 +445,9 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
         prof_begin(label, bytes, s);
       }
+      if (p.lazy_unmapped() && bn::factor_needs_arrays(p, (size_t)(&g - p.fgroups.data()), fresh, it == 0 ? 1 : 0,
+                                                       it == iterations - 1 ? 1 : 0, reduce_last))
+        if (int rc = ensure_message_arrays(p)) return rc;
       int rc = bn::launch_factor_fast<T>(p, g, arena, cpts, fresh, it == 0 ? 1 : 0, it == iterations - 1 ? 1 : 0, reduce_last, s,
                                          it == iterations - 2 ? 1 : 0);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised factor kernel failed");
@@ -390,6 +488,8 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
       reduced_groups.push_back(&g);  // finalised below, after the generic finalize has filled the rest
       continue;
     }
+    if (p.lazy_unmapped() && bn::factor_needs_arrays(p, (size_t)(&g - p.fgroups.data()), 0, 1, 1, 0))
+      if (int rc = ensure_message_arrays(p)) return rc;
     prof_begin(flabel("em_counts", g), factor_bytes(p, g, true), s);
     int rc = bn::launch_em_fast<T>(p, g, arena, nchunks, partial, s);
     if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised EM kernel failed");
@@ -551,6 +651,7 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
   p.device_bytes = 0;
   BN_TRY_HIP(hipMalloc(&p.arena, (size_t)p.arena_elems * p.elem_size));
   p.device_bytes += p.arena_elems * (int64_t)p.elem_size;
+  BN_TRY(place_lazy_region(p));
   BN_TRY_HIP(hipMalloc(&p.cpts, (size_t)p.cpt_total * p.elem_size));
   p.device_bytes += p.cpt_total * (int64_t)p.elem_size;
   {
@@ -630,6 +731,9 @@ int bn_plan_create(int dtype, int64_t num_observations, int32_t num_nodes, const
     BN_TRY_HIP(hipGetLastError());
   }
   if (bn::prepare_fast(p) != 0) return bail(fail(BN_ERR_HIP, "device allocation for the specialised kernels failed"));
+  // a candidate that no fused kernel serves has its messages on the ordinary kernels' path: its
+  // arrays are needed from the first iteration on
+  if (!bn::candidates_all_fused(p)) BN_TRY(ensure_message_arrays(p));
   BN_TRY(p.dtype == BN_F32 ? reset_messages_t<float>(p, nullptr) : reset_messages_t<double>(p, nullptr));
   BN_TRY_HIP(hipStreamSynchronize(nullptr));
 #undef BN_TRY
@@ -660,6 +764,11 @@ int bn_plan_topology(const bn_plan* plan, int32_t* is_tree, int32_t* factor_grap
 int64_t bn_plan_cpt_elements(const bn_plan* plan) { return plan ? plan->p.cpt_total : -1; }
 
 int64_t bn_plan_device_bytes(const bn_plan* plan) { return plan ? plan->p.device_bytes : -1; }
+
+int64_t bn_plan_unmapped_bytes(const bn_plan* plan) {
+  if (!plan) return -1;
+  return plan->p.lazy_elems > 0 && !plan->p.lazy_mapped ? (int64_t)plan->p.lazy_bytes : 0;
+}
 
 int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
@@ -871,7 +980,7 @@ int bn_local_log_likelihoods(bn_plan* plan, int32_t node, void* out_dev, void* s
   if (node < 0 || node >= p.n_nodes) return fail(BN_ERR_INVALID, "node out of range");
   if (int rc = complete_pending(p, static_cast<hipStream_t>(stream))) return rc;
   if (int rc = settle_normalisers(p, static_cast<hipStream_t>(stream))) return rc;
-  return gather(p, p.c_off[node], -1, 1, out_dev, static_cast<hipStream_t>(stream));
+  return gather(p, p.c_off[node], bn::kNoArray, 1, out_dev, static_cast<hipStream_t>(stream));
 }
 
 int bn_marginal_single(bn_plan* plan, int32_t node, void* out_dev, void* stream) {
@@ -892,14 +1001,14 @@ int bn_get_message(bn_plan* plan, int32_t owner, int32_t slot, int32_t direction
   if (slot == -2) {
     if (p.observed_slot_of[owner] < 0) return fail(BN_ERR_INVALID, "node is not observed");
     if (int rc = settle_observations(p, static_cast<hipStream_t>(stream))) return rc;
-    return gather(p, p.obs_off[p.observed_slot_of[owner]], -1, p.states[owner], out_dev,
+    return gather(p, p.obs_off[p.observed_slot_of[owner]], bn::kNoArray, p.states[owner], out_dev,
                   static_cast<hipStream_t>(stream));
   }
   if (slot < -1 || slot >= (int32_t)p.parents[owner].size()) return fail(BN_ERR_INVALID, "slot out of range");
   if (direction != 0 && direction != 1) return fail(BN_ERR_INVALID, "direction must be 0 or 1");
   const bn::EdgeLayout& e = slot < 0 ? p.edges[owner] : p.edges[p.parent_edge_base[owner] + slot];
   if (int rc = materialize(p, static_cast<hipStream_t>(stream))) return rc;
-  return gather(p, direction == 0 ? e.v2f : e.f2v, -1, e.states, out_dev, static_cast<hipStream_t>(stream));
+  return gather(p, direction == 0 ? e.v2f : e.f2v, bn::kNoArray, e.states, out_dev, static_cast<hipStream_t>(stream));
 }
 
 int bn_marginal_family(bn_plan* plan, int32_t node, void* out_dev, void* stream) {

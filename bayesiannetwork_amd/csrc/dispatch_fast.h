@@ -368,7 +368,58 @@ inline int prepare_fast(Plan& p) {
       }
     }
   }
+  // which launches touch the lazy region (see variable_needs_arrays / factor_needs_arrays)
+  st.vgroup_lazy.assign(p.vgroups.size(), 0);
+  st.fgroup_lazy.assign(p.fgroups.size(), 0);
+  auto any_lazy = [&](const std::vector<int64_t>& offs) {
+    for (int64_t off : offs)
+      if (off != kNoArray && p.in_lazy(off)) return true;
+    return false;
+  };
+  for (size_t gi = 0; gi < p.vgroups.size(); ++gi)
+    st.vgroup_lazy[gi] = any_lazy(p.vgroups[gi].in_off) || any_lazy(p.vgroups[gi].out_off) ? 1 : 0;
+  for (size_t fi = 0; fi < p.fgroups.size(); ++fi)
+    st.fgroup_lazy[fi] = any_lazy(p.fgroups[fi].in_off) || any_lazy(p.fgroups[fi].out_off) ? 1 : 0;
+  for (auto& w : st.wide) {
+    const VariableGroup& g = p.vgroups[w.vgroup];
+    auto slot_lazy = [&](int32_t slot) {
+      const int64_t in = g.in_off[(size_t)w.vpos * g.num_inputs + slot], out = g.out_off[(size_t)w.vpos * g.num_inputs + slot];
+      return p.in_lazy(in) || (out != kNoArray && p.in_lazy(out));
+    };
+    for (int32_t slot : w.covered) w.covered_lazy = w.covered_lazy || slot_lazy(slot);
+    for (int32_t slot : w.uncovered) w.uncovered_lazy = w.uncovered_lazy || slot_lazy(slot);
+  }
   return 0;
+}
+
+// Does the variable-pass launch of group gi read or write a message array of the lazy region?
+// (Asked while that region has no memory yet: the caller then backs it before the launch.)
+inline bool variable_needs_arrays(const Plan& p, size_t gi, int32_t fresh) {
+  FastState* st = fast_state(p);
+  if (!st) return true;
+  if (st->vgroup_skip[gi]) return false;
+  if (!st->vgroup_wide[gi]) return st->vgroup_lazy[gi] != 0;
+  for (int32_t j : p.vgroups[gi].nodes) {
+    const WideNode& w = st->wide[st->wide_of_node[j]];
+    const bool fused = w.fused_fgroup >= 0;
+    if (w.uncovered_lazy) return true;
+    // covered slots: read by the standalone product, read and written by the standalone emission
+    if (w.covered_lazy && (!fused || (!fresh && !w.partials_valid))) return true;
+  }
+  return false;
+}
+
+// The same for the factor-pass launch of group fi.  A fused group touches its arrays when it starts
+// from stored messages or runs in full mode.
+inline bool factor_needs_arrays(const Plan& p, size_t fi, int32_t fresh, int32_t first_iteration, int32_t last_iteration,
+                                int32_t reduce_last) {
+  FastState* st = fast_state(p);
+  if (!st) return true;
+  if (!st->fgroup_lazy[fi]) return false;
+  if (!st->fused.count((int32_t)fi)) return true;
+  const bool from_arrays = !fresh && first_iteration;
+  const bool full = last_iteration && !reduce_last;
+  return from_arrays || full;
 }
 
 inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode& w, int32_t fresh) {
@@ -571,6 +622,31 @@ extern template int launch_leaf_family<float>(Plan&, FactorGroup&, FusedFamily&,
                                               int32_t, int32_t, int32_t, hipStream_t, bool, bool);
 extern template int launch_leaf_family<double>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, double*,
                                                const double*, int32_t, int32_t, int32_t, hipStream_t, bool, bool);
+
+inline bool any_pending_fast(const Plan& p) {
+  FastState* st = fast_state(p);
+  if (!st) return false;
+  for (auto& kv : st->fused)
+    if (kv.second.pending) return true;
+  return false;
+}
+
+// No kernel but the fused leaf-family ones touches the message arrays of the layout's leaf-family
+// candidates (Plan::lazy_candidate): each candidate is in a fused group, and the variable group it
+// belongs to is skipped as a whole (a group that also holds other nodes runs the ordinary variable
+// kernel over all its members, the fused leaves included).
+inline bool candidates_all_fused(const Plan& p) {
+  FastState* st = fast_state(p);
+  std::vector<char> fused(p.n_nodes, 0);
+  if (st)
+    for (auto& kv : st->fused)
+      for (int32_t j : p.fgroups[kv.first].nodes) fused[j] = 1;
+  for (int32_t j = 0; j < p.n_nodes; ++j) {
+    if (!p.lazy_candidate[j]) continue;
+    if (!fused[j] || !st->vgroup_skip[p.vgroup_of[j]]) return false;
+  }
+  return true;
+}
 
 // Re-run, in full mode, every leaf-family iteration that was only reduced.  Must precede
 // anything that reads or changes messages, evidence or CPTs.

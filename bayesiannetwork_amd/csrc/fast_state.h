@@ -34,6 +34,8 @@ struct WideNode {
   int32_t* part_exp = nullptr;
   double* scaled = nullptr;
   bool partials_valid = false;
+  // some covered / uncovered slot's message arrays lie in the plan's lazy region
+  bool covered_lazy = false, uncovered_lazy = false;
 };
 
 struct FusedFamily {
@@ -82,6 +84,8 @@ struct FastState {
   std::map<int32_t, FusedFamily> fused;       // factor group index -> fused family
   std::vector<char> vgroup_skip;              // variable groups whose every node a fused kernel serves
   std::vector<char> vgroup_wide;              // variable groups served by the wide-node path
+  // groups with a message array in the plan's lazy region (Plan::in_lazy)
+  std::vector<char> vgroup_lazy, fgroup_lazy;
   // parentless factor groups whose output (the prior, broadcast over observations) is already in
   // place: it only changes with the CPTs
   std::vector<char> root_written;

@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(512) variable_split_fast(float* __restrict__ a
 #pragma unroll
   for (int32_t i = 0; i < I; ++i) {
     const int64_t o = out_off[(int64_t)k * I + i];
-    dst[i] = o >= 0 ? arena + o + (t * S + wave * SQ) * kTile + col : nullptr;
-    const bool skip = fresh && o >= 0;  // a message slot that still holds its initial uniform value
+    dst[i] = o != kNoArray ? arena + o + (t * S + wave * SQ) * kTile + col : nullptr;
+    const bool skip = fresh && o != kNoArray;  // a message slot that still holds its initial uniform value
     const float* src = arena + in_off[(int64_t)k * I + i] + (t * S + wave * SQ) * kTile + col;
 #pragma unroll
     for (int32_t q = 0; q < SQ; ++q)
@@ -345,8 +345,8 @@ __global__ void __launch_bounds__(256) variable_big_fast(float* __restrict__ are
   for (int32_t i = 0; i < I; ++i) {
     const int64_t o = out_off[(int64_t)k * I + i];
     src[i] = arena + in_off[(int64_t)k * I + i];
-    dst[i] = o >= 0 ? arena + o : nullptr;
-    skip[i] = fresh && o >= 0;
+    dst[i] = o != kNoArray ? arena + o : nullptr;
+    skip[i] = fresh && o != kNoArray;
   }
 
   double sums[I][4];

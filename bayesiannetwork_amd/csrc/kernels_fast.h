@@ -30,7 +30,6 @@ struct tile_of {
   static constexpr int32_t value = sizeof(T) == 4 ? 256 : 128;
 };
 constexpr int32_t kWavesPerBlock = 4;
-constexpr int32_t kWideFanIn = 24;   // variable nodes with more inputs take the chunked path
 constexpr int32_t kWideMaxStates = 16;
 
 struct f4 {
@@ -251,7 +250,7 @@ __global__ void __launch_bounds__(256) variable_small_fast(T* __restrict__ arena
   rowv<T> in[I][S];
 #pragma unroll
   for (int32_t i = 0; i < I; ++i) {
-    const bool skip = fresh && out_off[(int64_t)k * I + i] >= 0;
+    const bool skip = fresh && out_off[(int64_t)k * I + i] != kNoArray;
     const T* src = arena + in_off[(int64_t)k * I + i];
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
@@ -376,7 +375,7 @@ __global__ void __launch_bounds__(256) variable_small_fast(T* __restrict__ arena
 #pragma unroll
   for (int32_t i = 0; i < I; ++i) {
     const int64_t dst = out_off[(int64_t)k * I + i];
-    if (dst < 0) continue;
+    if (dst == kNoArray) continue;
     double inv[W];
     if (i == I - 1) {
 #pragma unroll

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
   // are not read (the observation slot, whose output offset is -1, always is)
   const T uniform = (T)1 / (T)S;
   auto input = [&](int32_t i, int32_t s) -> T {
-    if (fresh && out_k[i] >= 0) return uniform;
+    if (fresh && out_k[i] != kNoArray) return uniform;
     return arena[msg_index(in_k[i], t, S, s, tile, lt)];
   };
 
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) variable_pass_generic(T* __restrict__ aren
 
   for (int32_t i = 0; i < I; ++i) {
     const int64_t dst = out_k[i];
-    if (dst < 0) continue;
+    if (dst == kNoArray) continue;
     // leave-one-out quotient, again as mantissa * 2^exponent
     int32_t xmax = kDeadExponent;
     for (int32_t s = 0; s < S; ++s) {
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) fill_uniform(T* __restrict__ arena, const
 // ---------------------------------------------------------------------------------
 // Tile layout -> row-major [N, S] product of up to two messages (single-node marginal,
 // SpaInferenceMachine._infer_single_node, spa_v3/spa_inference_machine.py:72-81; with
-// b_off < 0 it is a plain message read-out).   grid.x = ceil(N*S/256)
+// b_off == kNoArray it is a plain message read-out).   grid.x = ceil(N*S/256)
 template <typename T>
 __global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ arena, int64_t a_off, int64_t b_off,
                                                   T* __restrict__ out, int64_t N, int32_t S, int32_t tile) {
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256) gather_rows(const T* __restrict__ arena, 
   const int64_t t = n / tile;
   const int32_t lt = (int32_t)(n % tile);
   T v = arena[msg_index(a_off, t, S, s, tile, lt)];
-  if (b_off >= 0) v *= arena[msg_index(b_off, t, S, s, tile, lt)];
+  if (b_off != kNoArray) v *= arena[msg_index(b_off, t, S, s, tile, lt)];
   out[idx] = v;
 }
 

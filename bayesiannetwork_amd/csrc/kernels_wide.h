@@ -42,7 +42,7 @@ namespace bn {
 
 struct WideArgs {
   const int64_t* in_off;   // [I]  this node's input offsets (f2v arrays / observation)
-  const int64_t* out_off;  // [I]  matching output offsets (v2f arrays), -1 = dead
+  const int64_t* out_off;  // [I]  matching output offsets (v2f arrays), kNoArray = none
   int64_t c_off;
   int32_t I;
   // partial products
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
   const T uniform = 1.0f / (T)S;
   for (int32_t u = 0; u < a.n_uncovered; ++u) {
     const int32_t i = a.uncovered[u];
-    const bool skip = a.fresh && a.out_off[i] >= 0;
+    const bool skip = a.fresh && a.out_off[i] != kNoArray;
     const T* src = arena + a.in_off[i] + t * S * tile_of<T>::value + col;
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
   for (int32_t u = 0; u < a.n_uncovered; ++u) {
     const int32_t i = a.uncovered[u];
     const int64_t dst = a.out_off[i];
-    if (dst < 0) continue;
+    if (dst == kNoArray) continue;
     const bool skip = a.fresh != 0;
     const T* src = arena + a.in_off[i] + t * S * tile_of<T>::value + col;
     double q[S];
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) wide_emit_fast(float* __restrict__ arena,
   for (int32_t j = first; j < last; ++j) {
     const int32_t i = a.covered[j];
     const int64_t dst = a.out_off[i];
-    if (dst < 0) continue;
+    if (dst == kNoArray) continue;
     const float* src = arena + a.in_off[i];
     double q[S][4];
     double sum[4] = {0.0, 0.0, 0.0, 0.0};

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 
@@ -139,21 +140,38 @@ std::string compile_plan(Plan& p, int dtype, int64_t num_observations, int32_t n
     p.parent_edge_base[j] = (int64_t)p.edges.size();
     for (int32_t q : p.parents[j]) p.edges.push_back({j, q, p.states[q], 0, 0});
   }
+  // Leaf-family candidates: childless nodes with one or two parents, all of them wide.  Their
+  // message arrays go to the end of the layout (the lazy region, see plan.h).
+  p.lazy_candidate.assign(num_nodes, 0);
+  const char* lazy_knob = getenv("BN_LAZY_ARRAYS");  // "0": every array in the arena, allocated at creation
+  const bool lazy_allowed = !(lazy_knob && lazy_knob[0] == '0');
+  for (int32_t j = 0; j < num_nodes && lazy_allowed; ++j) {
+    if (!p.children[j].empty() || p.parents[j].empty() || p.parents[j].size() > 2) continue;
+    bool wide = true;
+    for (int32_t q : p.parents[j]) {
+      const int32_t fan_in = (int32_t)p.children[q].size() + 1 + (p.observed_slot_of[q] >= 0 ? 1 : 0);
+      wide = wide && fan_in > kWideFanIn;
+    }
+    p.lazy_candidate[j] = wide ? 1 : 0;
+  }
   // factor -> variable messages first, grouped by receiving variable (its fan-in is read
   // together by the variable pass), then variable -> factor grouped by receiving factor.
-  {
-    std::vector<std::vector<int64_t>> by_var(num_nodes);
-    for (int64_t e = 0; e < (int64_t)p.edges.size(); ++e) by_var[p.edges[e].var].push_back(e);
+  std::vector<std::vector<int64_t>> by_var(num_nodes);
+  for (int64_t e = 0; e < (int64_t)p.edges.size(); ++e) by_var[p.edges[e].var].push_back(e);
+  auto lay_messages = [&](bool lazy) {
     for (int32_t v = 0; v < num_nodes; ++v)
-      for (int64_t e : by_var[v]) p.edges[e].f2v = take(p.edges[e].states);
+      for (int64_t e : by_var[v])
+        if ((p.lazy_candidate[p.edges[e].owner] != 0) == lazy) p.edges[e].f2v = take(p.edges[e].states);
     for (int32_t j = 0; j < num_nodes; ++j) {
+      if ((p.lazy_candidate[j] != 0) != lazy) continue;
       for (size_t q = 0; q < p.parents[j].size(); ++q) {
         EdgeLayout& e = p.edges[p.parent_edge_base[j] + q];
         e.v2f = take(e.states);
       }
       p.edges[j].v2f = take(p.states[j]);
     }
-  }
+  };
+  lay_messages(false);
   p.obs_off.resize(num_observed);
   for (int32_t i = 0; i < num_observed; ++i) p.obs_off[i] = take(p.states[p.observed[i]]);
   p.c_base = cursor;
@@ -169,6 +187,9 @@ std::string compile_plan(Plan& p, int dtype, int64_t num_observations, int32_t n
     p.ones_states = widest;
   }
   p.arena_elems = cursor;
+  p.lazy_begin = cursor;
+  lay_messages(true);
+  p.lazy_elems = cursor - p.lazy_begin;
 
   // ---- variable groups
   {
@@ -196,7 +217,7 @@ std::string compile_plan(Plan& p, int dtype, int64_t num_observations, int32_t n
         }
         if (p.observed_slot_of[j] >= 0) {
           g.in_off.push_back(p.obs_off[p.observed_slot_of[j]]);
-          g.out_off.push_back(-1);
+          g.out_off.push_back(kNoArray);
         }
         g.in_off.push_back(p.edges[j].f2v);
         g.out_off.push_back(p.edges[j].v2f);

@@ -19,7 +19,13 @@
 namespace bn {
 
 constexpr int kMaxArity = 8;        // parents + 1
+// Variable nodes with more inputs than this are "wide": their product is built from chunk partials,
+// and childless families under them are candidates for the fused leaf-family kernels.
+constexpr int32_t kWideFanIn = 24;
 constexpr int kMaxStatesGeneric = 256;
+// Stands for "no array" where an offset is expected.  Real offsets may be negative (an array can
+// lie below the arena's base address), so the sign of an offset says nothing.
+constexpr int64_t kNoArray = INT64_MIN;
 
 struct EdgeLayout {
   int32_t owner;   // node whose factor is one end
@@ -79,8 +85,18 @@ struct Plan {
   std::vector<int64_t> cpt_off;           // per node, into flat CPT buffer
   std::vector<std::vector<int32_t>> cpt_dims;
   int64_t cpt_total = 0;
-  int64_t arena_elems = 0;
+  int64_t arena_elems = 0;  // elements of the arena proper (allocated at creation)
   int64_t c_base = 0;  // c arrays are contiguous: [n_nodes][npad] starting here
+  // Message arrays of leaf-family candidates (childless nodes with one or two wide parents) are laid
+  // out after everything else, from lazy_begin on: the fused kernels keep those messages in
+  // registers and only a query makes them write the arrays, so their memory is a separate region
+  // that is backed on first use (an EM-only run never needs it).
+  int64_t lazy_begin = 0, lazy_elems = 0;
+  std::vector<char> lazy_candidate;  // per node
+  // final offsets (relative to `arena`) of the lazy region: [lazy_lo, lazy_hi)
+  int64_t lazy_lo = 0, lazy_hi = 0;
+  bool in_lazy(int64_t off) const { return off >= lazy_lo && off < lazy_hi; }
+  bool lazy_unmapped() const { return lazy_elems > 0 && !lazy_mapped; }
 
   std::vector<VariableGroup> vgroups;
   std::vector<FactorGroup> fgroups;
@@ -91,6 +107,13 @@ struct Plan {
 
   // device memory
   void* arena = nullptr;
+  // the lazy region: an address range reserved at creation (offsets of its arrays are relative to
+  // `arena` like all others), mapped to memory by the first call that reads or writes messages
+  void* lazy_base = nullptr;
+  size_t lazy_bytes = 0;
+  bool lazy_reserved = false;  // address range from hipMemAddressReserve (else an ordinary allocation)
+  bool lazy_mapped = false;
+  hipMemGenericAllocationHandle_t lazy_handle{};
   void* cpts = nullptr;        // flat CPT snapshot
   double* scratch = nullptr;   // reduction partials
   int64_t scratch_elems = 0;

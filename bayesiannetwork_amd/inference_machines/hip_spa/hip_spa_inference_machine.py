@@ -551,3 +551,8 @@ class HipSpaInferenceMachine(IInferenceMachine):
     @property
     def device_bytes(self) -> int:
         return self._lib.bn_plan_device_bytes(self._plan)
+
+    @property
+    def unmapped_bytes(self) -> int:
+        """Bytes of message arrays that exist as addresses only (no query has needed them yet)."""
+        return self._lib.bn_plan_unmapped_bytes(self._plan)

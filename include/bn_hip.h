@@ -88,6 +88,17 @@ int64_t bn_plan_cpt_elements(const bn_plan* plan);
 int64_t bn_plan_device_bytes(const bn_plan* plan);
 
 /*
+ * Bytes of message arrays that have an address but no memory yet.  Where a wide node's childless
+ * families run on the fused kernels, their messages live in registers and the arrays a query
+ * would read (FactorNodeGroup / VariableNodeGroup buffers of those families,
+ * spa_v3/factor_graph.py:48-60, :197-213) are only backed by memory when the first call that reads
+ * or writes messages arrives (bn_iterate, marginals, bn_get_message, bn_em_accumulate); a run of
+ * bn_em_statistics* calls never needs them.  0 once they are backed (then counted in
+ * bn_plan_device_bytes) or when the plan has no such arrays.
+ */
+int64_t bn_plan_unmapped_bytes(const bn_plan* plan);
+
+/*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
  * Replaces torch.stack(node.cpt ...) in FactorNodeGroup.__init__
  * (spa_v3/factor_graph.py:192).

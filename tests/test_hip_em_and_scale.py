@@ -443,3 +443,51 @@ def test_full_batch_em_never_lowers_the_likelihood_on_sampled_data():
     for before, after in zip(lls, lls[1:]):
         assert after >= before - 1e-5 * abs(before), lls
     assert lls[-1] > lls[0] + 0.1
+
+
+@pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32", "c3a_784_f64"])
+def test_message_arrays_of_fused_families_are_backed_on_first_use(name):
+    """A statistics-only run never touches the message arrays of the fused leaf families, so they
+    exist as addresses only; the first query backs them with memory and must see exactly what a
+    plan that had them from the start sees."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    ts = TorchSettings(device="cuda", dtype=fx.meta["dtype"])
+    network, observed, by_name = fx.build(ts)
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=fx.meta["num_iterations"],
+                                           allow_loops=fx.meta["allow_loops"])
+    n = fx.meta["N"]
+    evidence = Evidence([e.cuda() for e in fx.evidence_tensors()], ts)
+
+    lazy = HipSpaInferenceMachine(settings, network, observed, n)
+    held_back = lazy.unmapped_bytes
+    # all four (six) messages of the 784 families, each states x observations elements
+    assert held_back >= 784 * 2 * 4 * 256 * (4 if fx.dtype == torch.float32 else 8) // 2
+    ll_lazy, counts_lazy = lazy.em_statistics(evidence)
+    torch.cuda.synchronize()
+    assert lazy.unmapped_bytes == held_back, "a statistics call must not need the message arrays"
+
+    eager = HipSpaInferenceMachine(settings, network, observed, n)
+    eager.enter_evidence(evidence)
+    eager.infer_single_nodes([observed[0]])  # a query backs the arrays right away
+    assert eager.unmapped_bytes == 0
+    eager.reset_messages()  # back to the state of a new machine, arrays in place
+    ll_eager, counts_eager = eager.em_statistics(evidence)
+    assert ll_lazy.item() == ll_eager.item() and torch.equal(counts_lazy, counts_eager)
+
+    probe = [by_name["Q"], observed[0], observed[391], observed[-1]]
+    singles = lazy.infer_single_nodes(probe)
+    assert lazy.unmapped_bytes == 0 and lazy.device_bytes >= held_back
+    for a, b in zip(singles, eager.infer_single_nodes(probe)):
+        assert torch.equal(a, b)
+    for a, b in zip(lazy.infer_nodes_with_parents(probe), eager.infer_nodes_with_parents(probe)):
+        assert torch.equal(a, b)
+    parent = list(network.parents_of(observed[5]))[0]
+    assert torch.equal(lazy.message(parent, observed[5], "v2f"), eager.message(parent, observed[5], "v2f"))
+    # and a second batch on the now fully backed plan
+    ll2_lazy, c2_lazy = lazy.em_statistics(evidence)
+    ll2_eager, c2_eager = eager.em_statistics(evidence)
+    assert ll2_lazy.item() == ll2_eager.item() and torch.equal(c2_lazy, c2_eager)
