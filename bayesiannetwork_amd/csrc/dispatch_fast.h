@@ -466,7 +466,15 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
       if (!launch_ok()) return false;
     }
   }
-  {
+  if (!fresh && p.ntiles <= kCombineStatesMaxTiles && (int32_t)w.uncovered.size() <= kMaxUncovered) {
+    // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
+    const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_states<T, S>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;
+    launch(wide_combine_states<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
+  } else {
     // waves per block: one per group of four chunks, none to spare while the messages are fresh
     const int32_t nw = fresh ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
     launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw),

@@ -13,7 +13,6 @@
 
 namespace bn {
 
-constexpr int32_t kMaxUncovered = 8;
 // observations per lane in the leaf-family kernel: 4 leaves one wave per SIMD, 1 doubles the
 // per-family instruction overhead (both measured slower on the 784-leaf model)
 constexpr int32_t kLeafVec = 2;

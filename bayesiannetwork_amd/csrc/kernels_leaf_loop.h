@@ -253,7 +253,14 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
         request(source, i % R);
         const int32_t ka = k + R + 1 < last ? k + R + 1 : last - 1;
         ahead_off = INGEST ? src_tab[ka] : obs_tab[ka];
-        wait_vmcnt<kAhead>();
+        // family i + 1 must have arrived.  Younger than its DMAs are, in the steady state, R - 1
+        // families' worth of operations; during the first R - 1 iterations fewer of the other
+        // operations have been issued, and only the DMAs can be relied on to be there
+        if (kOther == 0 || i >= R - 1) {
+          wait_vmcnt<kAhead>();
+        } else {
+          wait_vmcnt<(R - 1) * ND>();
+        }
       } else {
         wait_vmcnt<0>();
       }

@@ -134,6 +134,8 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
 // it wants the chunk walk as parallel as it can get.
 //   grid.x = ntiles * 4, block = 64 * nw (nw <= kCombineMaxWaves), dynamic LDS = combine_lds_bytes<S>(nw)
 constexpr int32_t kCombineMaxWaves = 8;
+// up to this many tiles the per-state combine (wide_combine_states) is the faster one
+constexpr int64_t kCombineStatesMaxTiles = 32;
 template <int S>
 constexpr size_t combine_lds_bytes(int32_t nw) {
   return nw > 1 ? (size_t)nw * S * 64 * (sizeof(double) + sizeof(int32_t)) : 0;
@@ -260,6 +262,117 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
     T* out = arena + dst + t * S * tile_of<T>::value + col;
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) out[s * tile_of<T>::value] = (T)(q[s] * sum);
+  }
+}
+
+// The same combine for small batches, where a launch is a handful of blocks and its duration is the
+// length of its longest dependent chain: one wave per state, so that a wave's loads of all chunk
+// partials are in flight together (one round trip instead of one per group of chunks) and no wave
+// merges the others' products one after the other.
+//   grid.x = ntiles * tile / 64, block = 64 * S, dynamic LDS = combine_states_lds_bytes<S>(n_uncovered)
+template <int S>
+constexpr size_t combine_states_lds_bytes(int32_t n_uncovered) {
+  return (size_t)S * 64 * (sizeof(double) + sizeof(int32_t)) + (size_t)n_uncovered * S * 64 * sizeof(double);
+}
+
+template <typename T, int S>
+__global__ void __launch_bounds__(64 * S) wide_combine_states(T* __restrict__ arena, WideArgs a) {
+  extern __shared__ __align__(16) unsigned char combine_lds[];
+  double* lds_m = reinterpret_cast<double*>(combine_lds);                                    // [S][64]
+  int32_t* lds_e = reinterpret_cast<int32_t*>(combine_lds + (size_t)S * 64 * sizeof(double));  // [S][64]
+  double* lds_q = reinterpret_cast<double*>(combine_lds + (size_t)S * 64 * (sizeof(double) + sizeof(int32_t)));  // [n_uncovered][S][64]
+  const int32_t s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // this wave's state
+  const int64_t slice = blockIdx.x;
+  const int64_t t = slice / (tile_of<T>::value / 64);
+  const int32_t col = (int32_t)(slice % (tile_of<T>::value / 64)) * 64 + lane;
+  const int64_t n = t * tile_of<T>::value + col;
+
+  double m = a.fresh ? a.fresh_mant : 1.0;
+  int32_t e = a.fresh ? a.fresh_exp : 0;
+  if (!a.fresh) {
+    // mantissas lie in [0.5, 1) or are 0: sixteen of them multiply without leaving double range
+    for (int32_t ch = 0; ch < a.chunks; ch += 16) {
+      double pm[16];
+      int32_t pe[16];
+#pragma unroll
+      for (int32_t u = 0; u < 16; ++u) {
+        const bool live = ch + u < a.chunks;
+        const int64_t row = ((int64_t)(live ? ch + u : ch) * S + s) * a.npad + n;
+        pm[u] = a.part_mant[row];
+        pe[u] = a.part_exp[row];
+        if (!live) {
+          pm[u] = 1.0;
+          pe[u] = 0;
+        }
+      }
+#pragma unroll
+      for (int32_t u = 0; u < 16; ++u) {
+        m *= pm[u];
+        e += pe[u];
+      }
+      int de = 0;
+      m = frexp(m, &de);
+      e += de;
+    }
+  }
+  // inputs no partial covers (their values are needed again for the outgoing messages)
+  const T uniform = 1.0f / (T)S;
+  T x[kMaxUncovered];
+#pragma unroll
+  for (int32_t u = 0; u < kMaxUncovered; ++u) {
+    if (u < a.n_uncovered) {
+      const int32_t i = a.uncovered[u];
+      const bool skip = a.fresh && a.out_off[i] != kNoArray;
+      x[u] = skip ? uniform : arena[a.in_off[i] + (t * S + s) * tile_of<T>::value + col];
+      int de = 0;
+      m = frexp(m * (double)x[u], &de);
+      e += de;
+    }
+  }
+  {
+    int de = 0;
+    m = frexp(m, &de);
+    e = m == 0.0 ? kDeadExponent : e + de;
+  }
+  lds_m[s * 64 + lane] = m;
+  lds_e[s * 64 + lane] = e;
+  __syncthreads();
+  int32_t emax = kDeadExponent;
+#pragma unroll
+  for (int32_t j = 0; j < S; ++j) {
+    const int32_t ej = lds_e[j * 64 + lane];
+    emax = ej > emax ? ej : emax;
+  }
+  double z = 0.0;
+#pragma unroll
+  for (int32_t j = 0; j < S; ++j) z += ldexp(lds_m[j * 64 + lane], clamp_shift(lds_e[j * 64 + lane] - emax));
+  const double scaled = ldexp(m, clamp_shift(e - emax));  // P'[s]
+  if (s == 0) arena[a.c_off + n] = (T)((double)emax * 0.6931471805599453 + log(z));
+  a.scaled[(int64_t)s * a.npad + n] = scaled;
+  // outgoing messages of the uncovered inputs: P' / input, normalised over the states (the message to
+  // the local factor by z, as the reference's variable pass does)
+#pragma unroll
+  for (int32_t u = 0; u < kMaxUncovered; ++u) {
+    if (u < a.n_uncovered) {
+      const T xin = (a.fresh != 0) ? uniform : x[u];
+      lds_q[(u * S + s) * 64 + lane] = scaled / (double)xin;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int32_t u = 0; u < kMaxUncovered; ++u) {
+    if (u < a.n_uncovered) {
+      const int32_t i = a.uncovered[u];
+      const int64_t dst = a.out_off[i];
+      if (dst != kNoArray) {
+        double sum = 0.0;
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) sum += lds_q[(u * S + j) * 64 + lane];
+        const bool local = (i == a.I - 1);
+        sum = 1.0 / (local ? z : sum);
+        arena[dst + (t * S + s) * tile_of<T>::value + col] = (T)(lds_q[(u * S + s) * 64 + lane] * sum);
+      }
+    }
   }
 }
 

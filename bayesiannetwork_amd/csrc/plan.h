@@ -23,6 +23,9 @@ constexpr int kMaxArity = 8;        // parents + 1
 // and childless families under them are candidates for the fused leaf-family kernels.
 constexpr int32_t kWideFanIn = 24;
 constexpr int kMaxStatesGeneric = 256;
+// inputs of a wide node that its combine kernel folds in one by one (everything else reaches it as
+// chunk partial products)
+constexpr int32_t kMaxUncovered = 8;
 // Stands for "no array" where an offset is expected.  Real offsets may be negative (an array can
 // lie below the arena's base address), so the sign of an offset says nothing.
 constexpr int64_t kNoArray = INT64_MIN;
