@@ -321,6 +321,12 @@ inline int prepare_fast(Plan& p) {
     if (p.ntiles >= 16) want = std::min<int64_t>(want, 32);
     if (env_wide_chunks() > 0) want = env_wide_chunks();
     int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, n / 8));
+    // Small batches: the waves of a block share a chunk (FusedFamily::split), so the same number of
+    // waves leaves a quarter of the partials for the combine to read.  One-parent groups only (the
+    // loop launches of two-parent groups have no such mode).
+    bool share = w.fused_fgroup >= 0 && p.ntiles * leaf_parts(p) <= env_share_max() && chunks >= 2 * kWavesPerBlock;
+    for (int32_t fi : w.fused_fgroups) share = share && st.fused[fi].wide_index2 < 0;
+    if (share) chunks /= kWavesPerBlock;
     // the leaf-family kernel keeps a chunk's exponents in 16 bits
     if (w.fused_fgroup >= 0) chunks = std::max(chunks, (n + kLeafMaxChunkLen - 1) / kLeafMaxChunkLen);
     w.chunk_len = (n + chunks - 1) / chunks;
@@ -334,6 +340,7 @@ inline int prepare_fast(Plan& p) {
         FusedFamily& fam = st.fused[fi];
         const int32_t members = (int32_t)p.fgroups[fi].nodes.size();
         fam.chunk_len = w.chunk_len;
+        fam.split = share ? kWavesPerBlock : 1;
         fam.chunks = (members + w.chunk_len - 1) / w.chunk_len;
         fam.chunk_base = w.chunks;
         for (int32_t c = 0; c < fam.chunks; ++c) chunk_first.push_back(group_first + c * w.chunk_len);
@@ -466,7 +473,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
       if (!launch_ok()) return false;
     }
   }
-  if (!fresh && p.ntiles <= kCombineStatesMaxTiles && (int32_t)w.uncovered.size() <= kMaxUncovered) {
+  if (!fresh && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
     // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
     const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
     if (lds > 48 * 1024 &&

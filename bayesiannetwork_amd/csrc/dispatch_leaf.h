@@ -201,7 +201,17 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   a.src = fam.d_src;
   a.on_value = (T)fast_state(p)->ingest_on;
   a.off_value = (T)fast_state(p)->ingest_off;
+  a.split = loop_p1 ? fam.split : 1;
   int64_t waves = (int64_t)fam.chunks * p.ntiles * leaf_parts(p);
+  if (a.split > 1) {
+    // one block per work item, and room for the quarters' products to meet (after the rings)
+    waves *= kWavesPerBlock;
+    lds_bytes += (size_t)(kWavesPerBlock - 1) * (g.dims[0] * 2 + 4) * 64 * (sizeof(double) + sizeof(int32_t));
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return -1;
+  }
   if (wide4) {
     const int32_t K = (int32_t)g.nodes.size();
     a.chunk_len = (K + chunks_r - 1) / chunks_r;

@@ -41,6 +41,8 @@ struct FusedFamily {
   int32_t wide_index = -1;
   int32_t wide_index2 = -1;     // second wide parent of two-parent families, else -1
   int32_t chunk_base = 0, chunks = 0, chunk_len = 0;  // this group's range of the parent's chunk partials
+  // loop launches of a one-parent group: waves that share a chunk (1, or kWavesPerBlock for small batches)
+  int32_t split = 1;
   void* m_state = nullptr;      // [K][D0 + D1][npad] of the plan's element type: two-parent loop state (previous messages to the parents)
   int64_t* d_obs_off = nullptr;
   int64_t* d_c_off = nullptr;
@@ -113,6 +115,17 @@ inline int32_t env_wide_chunks() {
 }
 inline int32_t env_reduce_chunks() {
   static const int32_t v = env_int("BN_REDUCE_CHUNKS");
+  return v;
+}
+// BN_SHARE_MAX=n  largest number of waves per chunk (tiles x parts) at which the waves of a block share a chunk
+// BN_COMBINE_STATES_MAX=n  largest number of tiles at which the per-state combine kernel runs (default: always;
+//                          measured faster at every batch size of the 784-leaf model)
+inline int32_t env_share_max() {
+  static const int32_t v = getenv("BN_SHARE_MAX") ? env_int("BN_SHARE_MAX") : 16;
+  return v;
+}
+inline int32_t env_combine_states_max() {
+  static const int32_t v = getenv("BN_COMBINE_STATES_MAX") ? env_int("BN_COMBINE_STATES_MAX") : (1 << 30);
   return v;
 }
 inline bool env_reduce_v2() {

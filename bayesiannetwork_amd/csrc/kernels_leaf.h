@@ -43,6 +43,10 @@ struct LeafFamilyArgs {
   // leaf, or the leaf's stand-in observation array in the arena (all ones) when it is not observed
   const void* const* src;
   T on_value, off_value;  // evidence given as states: what an observed / any other state's row receives
+  // leaf_loop_p1 only: 1, or kWavesPerBlock when the waves of a block share one (chunk, tile, part)
+  // work item, each taking a quarter of the chunk's families (small batches: as many waves as
+  // before, a quarter of the chunk partials for the parent's combine to read)
+  int32_t split;
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state is written (one-parent families run

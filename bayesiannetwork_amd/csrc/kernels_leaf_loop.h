@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   extern __shared__ __align__(16) unsigned char ring_raw[];
 
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const bool split = a.split > 1;  // the block's waves share one work item (uniform over the block)
+  int64_t w = split ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
   const int32_t part = (int32_t)(w % kParts);
   w /= kParts;
@@ -100,9 +101,20 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   const int64_t t = w % a.ntiles;
   const int32_t col = part * 64 * V + lane * V;  // first observation of this lane inside the tile
   const int64_t obs0 = t * tile_of<T>::value + col;
-  const int32_t first = chunk * a.chunk_len;
-  const int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
+  int32_t first = chunk * a.chunk_len;
+  int32_t last = first + a.chunk_len < a.K ? first + a.chunk_len : a.K;
   if (first >= last) return;
+  // A wave of a sharing block whose quarter is empty walks the chunk's last family instead and
+  // contributes nothing (it has to reach the block's barrier anyway).
+  bool spare = false;
+  if (split) {
+    const int32_t quarter = (last - first + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int32_t lo = first + wave * quarter;
+    const int32_t hi = lo + quarter < last ? lo + quarter : last;
+    spare = lo >= hi;
+    first = spare ? last - 1 : lo;
+    last = spare ? last : hi;
+  }
   const int32_t n = last - first;
 
   const_table_ptr obs_tab = (const_table_ptr)a.obs_off;
@@ -191,7 +203,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   // prod_k z_k of this iteration (read, or multiplied up below) and of the next one
   double zin_m[V] = {1.0, 1.0};
   int32_t zin_e[V] = {0, 0};
-  if constexpr (STATE == kLoopChunk) {
+  if (STATE == kLoopChunk && !(split && wave > 0)) {
     const double2 m = *reinterpret_cast<const double2*>(a.zc_mant + (int64_t)chunk * a.npad + obs0);
     const int2 e = *reinterpret_cast<const int2*>(a.zc_exp + (int64_t)chunk * a.npad + obs0);
     zin_m[0] = m.x;
@@ -341,6 +353,73 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     }
 #pragma unroll
     for (int32_t j = 0; j < E; ++j) cpt_cur[j] = cpt_nxt[j];
+  }
+  if (split) {
+    // the four quarters' products meet in wave 0 (every factor brought to [0.5, 1) first)
+    double* mm = reinterpret_cast<double*>(ring_raw + kWavesPerBlock * Ring::kWaveBytes);
+    constexpr int32_t kDoubles = D0 * V + 2 * V, kInts = D0 * V + 2 * V;
+    int32_t* me = reinterpret_cast<int32_t*>(mm + (size_t)(kWavesPerBlock - 1) * kDoubles * 64);
+#pragma unroll
+    for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        pe[d][v] += (short)frexp_in_place(pm[d][v]);
+        if (spare) {
+          pm[d][v] = 0.5;
+          pe[d][v] = 1;
+        }
+      }
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      pze[v] += frexp_in_place(pz[v]);
+      if (STATE != kLoopChunk || wave == 0) zin_e[v] += frexp_in_place(zin_m[v]);
+      if (spare) {
+        pz[v] = 0.5;
+        pze[v] = 1;
+        zin_m[v] = 0.5;
+        zin_e[v] = 1;
+      }
+    }
+    if (wave > 0) {
+      double* dm = mm + (size_t)(wave - 1) * kDoubles * 64;
+      int32_t* de = me + (size_t)(wave - 1) * kInts * 64;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          dm[(d * V + v) * 64 + lane] = pm[d][v];
+          de[(d * V + v) * 64 + lane] = pe[d][v];
+        }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        dm[(D0 * V + v) * 64 + lane] = pz[v];
+        de[(D0 * V + v) * 64 + lane] = pze[v];
+        dm[(D0 * V + V + v) * 64 + lane] = zin_m[v];
+        de[(D0 * V + V + v) * 64 + lane] = zin_e[v];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int32_t j = 0; j < kWavesPerBlock - 1; ++j) {
+      const double* dm = mm + (size_t)j * kDoubles * 64;
+      const int32_t* de = me + (size_t)j * kInts * 64;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          pm[d][v] *= dm[(d * V + v) * 64 + lane];
+          pe[d][v] += (short)de[(d * V + v) * 64 + lane];
+        }
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        pz[v] *= dm[(D0 * V + v) * 64 + lane];
+        pze[v] += de[(D0 * V + v) * 64 + lane];
+        if constexpr (STATE != kLoopChunk) {
+          zin_m[v] *= dm[(D0 * V + V + v) * 64 + lane];
+          zin_e[v] += de[(D0 * V + V + v) * 64 + lane];
+        }
+      }
+    }
   }
   if constexpr (!LAST) {
     double2 m;

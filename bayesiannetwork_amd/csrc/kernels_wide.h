@@ -134,8 +134,6 @@ __global__ void __launch_bounds__(256) wide_product_fast(const float* __restrict
 // it wants the chunk walk as parallel as it can get.
 //   grid.x = ntiles * 4, block = 64 * nw (nw <= kCombineMaxWaves), dynamic LDS = combine_lds_bytes<S>(nw)
 constexpr int32_t kCombineMaxWaves = 8;
-// up to this many tiles the per-state combine (wide_combine_states) is the faster one
-constexpr int64_t kCombineStatesMaxTiles = 32;
 template <int S>
 constexpr size_t combine_lds_bytes(int32_t nw) {
   return nw > 1 ? (size_t)nw * S * 64 * (sizeof(double) + sizeof(int32_t)) : 0;
