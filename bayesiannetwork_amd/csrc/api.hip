@@ -19,8 +19,22 @@
 #include "kernels_generic.h"
 #include "plan.h"
 
+// A captured EM-statistics launch sequence (see bn_em_statistics).
+struct StepGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int32_t seen = 0;       // calls that arrived with this signature
+  int32_t ll_blocks = 0;  // partial sums the sequence leaves for the final log-likelihood sum
+};
+
 struct bn_plan {
   bn::Plan p;
+  std::map<std::string, StepGraph> graphs;  // by signature of the plan's state and the call's arguments
+  hipStream_t capture_stream = nullptr;     // only ever captured on, never run
+  double* accum_slot = nullptr;             // where a captured sequence leaves the count sums
+  bool graphs_off = false;                  // set for the duration of a call that must not allocate
+  bool graphs_wanted = true;                // bn_plan_enable_step_graphs
+  int64_t graph_launches = 0;
 };
 
 namespace {
@@ -586,6 +600,142 @@ int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStrea
   return BN_OK;
 }
 
+// Partial sums of the log-likelihood over all normaliser arrays into p.scratch; returns their number.
+int ll_partial_launch(bn::Plan& p, hipStream_t s, int32_t* blocks_out) {
+  const int64_t total = (int64_t)p.n_nodes * p.npad;
+  const int32_t blocks = (int32_t)std::min<int64_t>(kLlBlocks, (total + 255) / 256);
+  if (p.dtype == BN_F32) {
+    bn::launch(bn::ll_partial<float>, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const float*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  } else {
+    bn::launch(bn::ll_partial<double>, dim3(blocks), dim3(256), 0, s,
+                       static_cast<const double*>(p.arena) + p.c_base, (int64_t)p.n_nodes, p.N, p.npad, p.scratch);
+  }
+  BN_LAUNCH_CHECK("ll_partial");
+  *blocks_out = blocks;
+  return BN_OK;
+}
+
+// The launches of bn_em_statistics up to, not including, the final sum of the log-likelihood
+// partials (which writes to the caller's address): iterations with the last one in reduce mode,
+// log-likelihood partial sums into p.scratch (*ll_blocks of them), count sums into accum (if wanted).
+int statistics_launches(bn::Plan& p, int32_t num_iterations, int32_t reduce_last, double* accum, hipStream_t s,
+                        int32_t* ll_blocks) {
+  int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, reduce_last, s)
+                             : iterate_t<double>(p, num_iterations, reduce_last, s);
+  if (rc != BN_OK) return rc;
+  // the fused families left their normalisers as per-observation partial sums
+  const int used = bn::ll_partials_reduced(p, p.scratch, kLlBlocks, s);
+  if (used < 0) return fail(BN_ERR_HIP, "launch of ll_partial_listed failed");
+  if (used > 0) {
+    *ll_blocks = used;
+  } else {
+    if (int rc2 = complete_pending(p, s)) return rc2;
+    if (int rc2 = settle_normalisers(p, s)) return rc2;
+    if (int rc2 = ll_partial_launch(p, s, ll_blocks)) return rc2;
+  }
+  if (!accum) return BN_OK;
+  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum, true, s) : em_accumulate_t<double>(p, accum, true, s);
+}
+
+// BN_STEP_GRAPH=0 in the environment: never run launch sequences as captured graphs
+bool step_graphs_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("BN_STEP_GRAPH");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+// batches up to this many tiles (of 256 float / 128 double observations) are launch-bound
+constexpr int64_t kStepGraphMaxTiles = 64;
+
+void drop_step_graphs(bn_plan* plan) {
+  for (auto& kv : plan->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  plan->graphs.clear();
+}
+
+// Small batches are bound by the number of launches, not by what the kernels do.  A launch sequence
+// (`body`) that depends only on the plan's state and on `key` runs as one captured graph from the
+// third call on that finds the plan in the same state with the same key (captured on the second
+// such call; the first may still allocate or map memory).  The host-side bookkeeping of the
+// launches is then replayed without dispatching anything (bn::dry_launches).
+//   body(stream, in_graph, &ll_blocks): in_graph = its kernels run from a graph, so every address
+//   they are given must be the same in all later calls (plan-owned buffers only).
+template <typename Body>
+int run_sequence(bn_plan* plan, std::string key, int32_t num_iterations, hipStream_t s, bool* from_graph,
+                 int32_t* ll_blocks, Body body) {
+  bn::Plan& p = plan->p;
+  *from_graph = false;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (s) (void)hipStreamIsCapturing(s, &capturing);
+  (void)hipGetLastError();
+  const bool graphable = step_graphs_enabled() && plan->graphs_wanted && !plan->graphs_off &&
+                         !g_profiling.load(std::memory_order_relaxed) && p.ntiles <= kStepGraphMaxTiles &&
+                         capturing == hipStreamCaptureStatusNone;
+  if (!graphable) return body(s, false, ll_blocks);
+  {
+    auto put = [&](const auto& v) { key.append(reinterpret_cast<const char*>(&v), sizeof v); };
+    put(num_iterations);
+    put(p.fresh);
+    put(p.c_stale);
+    put(p.obs_pending);
+    put(p.lazy_mapped);
+    put(p.scratch);
+    put(p.scratch_elems);
+    bn::append_state_signature(p, key);
+  }
+  if (plan->graphs.size() > 16 && !plan->graphs.count(key)) drop_step_graphs(plan);
+  StepGraph& g = plan->graphs[key];
+  if (!g.exec && g.seen == 0) {
+    g.seen = 1;
+    return body(s, false, ll_blocks);
+  }
+  if (!plan->accum_slot) {
+    BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&plan->accum_slot), (size_t)std::max<int64_t>(p.cpt_total, 1) * sizeof(double)));
+    p.device_bytes += p.cpt_total * 8;
+  }
+  if (!g.exec) {
+    if (!plan->capture_stream) BN_HIP_CHECK(hipStreamCreateWithFlags(&plan->capture_stream, hipStreamNonBlocking));
+    BN_HIP_CHECK(hipStreamBeginCapture(plan->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body(plan->capture_stream, true, ll_blocks);
+    hipGraph_t graph = nullptr;
+    const hipError_t ended = hipStreamEndCapture(plan->capture_stream, &graph);
+    if (rc != BN_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      plan->graphs.erase(key);
+      return rc;
+    }
+    if (ended != hipSuccess || !graph) {
+      plan->graphs.erase(key);
+      return fail(BN_ERR_HIP, std::string("capturing the launch sequence: ") + hipGetErrorString(ended));
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t made = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (made != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      plan->graphs.erase(key);
+      return fail(BN_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(made));
+    }
+    g.graph = graph;
+    g.exec = exec;
+    g.ll_blocks = *ll_blocks;
+  } else {
+    bn::dry_launches() = true;
+    const int rc = body(s, true, ll_blocks);
+    bn::dry_launches() = false;
+    if (rc != BN_OK) return rc;
+    if (*ll_blocks != g.ll_blocks)
+      return fail(BN_ERR_STATE, "a replayed launch sequence took another course than the captured one");
+  }
+  BN_HIP_CHECK(hipGraphLaunch(g.exec, s));
+  ++plan->graph_launches;
+  *from_graph = true;
+  return BN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -747,6 +897,9 @@ int bn_plan_destroy(bn_plan* plan) {
   int prev = 0;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(plan->p.device);
+  drop_step_graphs(plan);
+  if (plan->capture_stream) (void)hipStreamDestroy(plan->capture_stream);
+  if (plan->accum_slot) (void)hipFree(plan->accum_slot);
   bn::release_fast(plan->p);
   release(plan->p);
   (void)hipSetDevice(prev);
@@ -769,6 +922,14 @@ int64_t bn_plan_unmapped_bytes(const bn_plan* plan) {
   if (!plan) return -1;
   return plan->p.lazy_elems > 0 && !plan->p.lazy_mapped ? (int64_t)plan->p.lazy_bytes : 0;
 }
+
+int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  plan->graphs_wanted = enabled != 0;
+  return BN_OK;
+}
+
+int64_t bn_plan_step_graph_launches(const bn_plan* plan) { return plan ? plan->graph_launches : -1; }
 
 int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
@@ -1060,26 +1221,27 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
   if (int rc = complete_pending(p, s)) return rc;
   if (int rc = settle_observations(p, s)) return rc;
   const int32_t reduce_last = accum_dev ? 1 : 2;
-  int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, reduce_last, s)
-                             : iterate_t<double>(p, num_iterations, reduce_last, s);
+  const double scale = average ? 1.0 / (double)p.N : 1.0;
+  auto finish = [&](int32_t ll_blocks) -> int {
+    prof_begin("log_likelihood", (double)p.N * 8.0, s);
+    bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, scale, ll_out_dev);
+    BN_LAUNCH_CHECK("sum_partials");
+    prof_end(s);
+    return BN_OK;
+  };
+  std::string key = "statistics";
+  key.append(reinterpret_cast<const char*>(&reduce_last), sizeof reduce_last);
+  bool from_graph = false;
+  int32_t ll_blocks = 0;
+  const int rc = run_sequence(plan, key, num_iterations, s, &from_graph, &ll_blocks,
+                              [&](hipStream_t on, bool in_graph, int32_t* blocks) {
+                                double* target = accum_dev && in_graph ? plan->accum_slot : accum_dev;
+                                return statistics_launches(p, num_iterations, reduce_last, target, on, blocks);
+                              });
   if (rc != BN_OK) return rc;
-  {
-    // the fused families left their normalisers as per-observation partial sums
-    const int used = bn::ll_partials_reduced(p, p.scratch, kLlBlocks, s);
-    if (used < 0) return fail(BN_ERR_HIP, "launch of ll_partial_listed failed");
-    if (used > 0) {
-      prof_begin("log_likelihood", (double)p.N * 8.0, s);
-      bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, used, average ? 1.0 / (double)p.N : 1.0,
-                         ll_out_dev);
-      BN_LAUNCH_CHECK("sum_partials");
-      prof_end(s);
-      rc = BN_OK;
-    } else {
-      rc = bn_log_likelihood(plan, average, ll_out_dev, stream);
-    }
-  }
-  if (rc != BN_OK || !accum_dev) return rc;
-  return p.dtype == BN_F32 ? em_accumulate_t<float>(p, accum_dev, true, s) : em_accumulate_t<double>(p, accum_dev, true, s);
+  if (from_graph && accum_dev)
+    BN_HIP_CHECK(hipMemcpyAsync(accum_dev, plan->accum_slot, (size_t)p.cpt_total * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return finish(ll_blocks);
 }
 
 int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev,
@@ -1106,6 +1268,12 @@ int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t avera
   } swap{p, p.scratch, p.scratch_elems};
   p.scratch = base;
   p.scratch_elems = kStaticScratchElems;
+  struct NoGraphs {
+    bn_plan* plan;
+    bool before;
+    ~NoGraphs() { plan->graphs_off = before; }
+  } no_graphs{plan, plan->graphs_off};
+  plan->graphs_off = true;  // capturing and instantiating a graph allocates
   return bn_em_statistics(plan, num_iterations, average, ll_out_dev, accum_dev, stream);
 }
 
@@ -1167,6 +1335,84 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
   return rc;
 }
 
+int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
+               double off_value, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
+               double* ll_out_dev, void* new_cpts_dev, void* stream) {
+  if (!plan || !ll_out_dev || !new_cpts_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
+  if (regularization < 0.0 || regularization > 1.0) return fail(BN_ERR_INVALID, "regularization must be in [0, 1]");
+  bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  if (!p.observed.empty() && !evidence_dev && !states_dev) return fail(BN_ERR_INVALID, "no evidence given");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // messages as a machine built for this batch would have them
+  if (int rc = p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s)) return rc;
+  // evidence: read by the first iteration itself where bn_em_statistics_from[_states] would do so
+  bool ingest = !p.observed.empty() && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0;
+  if (ingest && states_dev) {
+    ingest = reinterpret_cast<uintptr_t>(states_dev) % 2 == 0 && bn::ingest_states_possible(p);
+  } else if (ingest) {
+    ingest = bn::ingest_possible(p);
+    for (size_t i = 0; i < p.observed.size() && ingest; ++i)
+      ingest = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
+  }
+  if (!ingest) {
+    const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
+                              : bn_enter_evidence(plan, evidence_dev, stream);
+    if (rc != BN_OK) return rc;
+  } else {
+    if (int rc = upload_family_sources(p, states_dev ? nullptr : evidence_dev, s, states_dev)) return rc;
+    p.obs_pending = false;  // the first factor pass writes every observation array
+    if (states_dev) {
+      bn::set_ingest_next(p, true, true, on_value, off_value);
+    } else {
+      bn::set_ingest_next(p, true);
+    }
+  }
+  if (int rc = settle_observations(p, s)) return rc;
+  if (!plan->accum_slot) {
+    BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&plan->accum_slot), (size_t)std::max<int64_t>(p.cpt_total, 1) * sizeof(double)));
+    p.device_bytes += p.cpt_total * 8;
+  }
+  std::string key = "step";
+  key.append(reinterpret_cast<const char*>(&learning_rate), sizeof learning_rate);
+  key.append(reinterpret_cast<const char*>(&regularization), sizeof regularization);
+  bool from_graph = false;
+  int32_t ll_blocks = 0;
+  const int rc = run_sequence(
+      plan, key, num_iterations, s, &from_graph, &ll_blocks, [&](hipStream_t on, bool in_graph, int32_t* blocks) {
+        if (int rc2 = statistics_launches(p, num_iterations, 1, plan->accum_slot, on, blocks)) return rc2;
+        // M-step on the plan's own snapshot, in place; the caller's copy is written by the same kernel
+        // unless the kernel runs from a graph (the caller's address may differ from call to call)
+        const dim3 grid((uint32_t)((p.n_rows + 255) / 256));
+        prof_begin("m_step", 0.0, on);
+        if (p.dtype == BN_F32) {
+          bn::launch(bn::m_step_rows<float>, grid, dim3(256), 0, on, (const double*)plan->accum_slot,
+                     static_cast<const float*>(p.cpts), p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization,
+                     static_cast<float*>(p.cpts), in_graph ? nullptr : static_cast<float*>(new_cpts_dev));
+        } else {
+          bn::launch(bn::m_step_rows<double>, grid, dim3(256), 0, on, (const double*)plan->accum_slot,
+                     static_cast<const double*>(p.cpts), p.d_row_off, p.d_row_len, p.n_rows, learning_rate,
+                     regularization, static_cast<double*>(p.cpts), in_graph ? nullptr : static_cast<double*>(new_cpts_dev));
+        }
+        BN_LAUNCH_CHECK("m_step_rows");
+        prof_end(on);
+        // with new parameters every stored message is stale: the plan is as after bn_set_cpts + bn_reset_messages
+        bn::cpts_changed_fast(p);
+        return p.dtype == BN_F32 ? reset_messages_t<float>(p, on) : reset_messages_t<double>(p, on);
+      });
+  bn::set_ingest_next(p, false);
+  if (rc != BN_OK) return rc;
+  if (from_graph)
+    BN_HIP_CHECK(hipMemcpyAsync(new_cpts_dev, p.cpts, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice, s));
+  prof_begin("log_likelihood", (double)p.N * 8.0, s);
+  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, average ? 1.0 / (double)p.N : 1.0, ll_out_dev);
+  BN_LAUNCH_CHECK("sum_partials");
+  prof_end(s);
+  return BN_OK;
+}
+
 int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,
               double regularization, void* new_cpts_dev, void* stream) {
   if (!plan || !count_sums_dev || !new_cpts_dev) return fail(BN_ERR_INVALID, "null argument");
@@ -1179,10 +1425,12 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
   prof_begin("m_step", 0.0, s);
   if (p.dtype == BN_F32) {
     bn::launch(bn::m_step_rows<float>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const float*>(old_cpts_dev),
-               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<float*>(new_cpts_dev));
+               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<float*>(new_cpts_dev),
+               static_cast<float*>(nullptr));
   } else {
     bn::launch(bn::m_step_rows<double>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const double*>(old_cpts_dev),
-               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<double*>(new_cpts_dev));
+               p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<double*>(new_cpts_dev),
+               static_cast<double*>(nullptr));
   }
   BN_LAUNCH_CHECK("m_step_rows");
   prof_end(s);

@@ -685,6 +685,30 @@ inline int complete_pending_fast(Plan& p, hipStream_t s) {
   return 0;
 }
 
+// Everything of the specialised path's host state that decides which kernels an iteration
+// launches and with which arguments, as bytes appended to `key`.
+inline void append_state_signature(const Plan& p, std::string& key) {
+  FastState* st = fast_state(p);
+  if (!st) return;
+  auto put = [&](const auto& v) { key.append(reinterpret_cast<const char*>(&v), sizeof v); };
+  put(st->ingest_next);
+  put(st->ingest_states);
+  put(st->ingest_on);
+  put(st->ingest_off);
+  key.append(st->root_written.begin(), st->root_written.end());
+  for (const auto& w : st->wide) put(w.partials_valid);
+  for (const auto& kv : st->fused) {
+    const FusedFamily& fam = kv.second;
+    put(fam.pending);
+    put(fam.pending_fresh);
+    put(fam.pending_first);
+    put(fam.em_ready);
+    put(fam.z_form);
+    put(fam.ll_rows);
+    put(fam.slots_used);
+  }
+}
+
 inline bool em_is_reduced(const Plan& p, size_t fi) {
   FastState* st = fast_state(p);
   if (!st) return false;

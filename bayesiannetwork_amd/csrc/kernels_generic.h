@@ -490,7 +490,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) m_step_rows(const double* __restrict__ counts, const T* old_cpts,
                                                   const int64_t* __restrict__ row_off,
                                                   const int32_t* __restrict__ row_len, int64_t rows,
-                                                  double learning_rate, double regularization, T* out) {
+                                                  double learning_rate, double regularization, T* out, T* out2) {
 #pragma clang fp contract(off)
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
@@ -511,7 +511,8 @@ __global__ void __launch_bounds__(256) m_step_rows(const double* __restrict__ co
       const double b = learning_rate * x;
       x = a + b;
     }
-    out[off + j] = (T)x;
+    out[off + j] = (T)x;  // may be old_cpts itself: each entry is read before it is written, by the same thread
+    if (out2) out2[off + j] = (T)x;
   }
 }
 

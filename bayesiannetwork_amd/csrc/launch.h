@@ -19,6 +19,14 @@ inline LaunchEventSource& launch_event_source() {
   return source;
 }
 
+// While set (per thread), launch() does nothing: the host-side bookkeeping of a sequence of
+// launches is replayed without dispatching them (the kernels themselves then run from a captured
+// graph of the same sequence).
+inline bool& dry_launches() {
+  static thread_local bool dry = false;
+  return dry;
+}
+
 template <typename T>
 struct launch_param {
   using type = T;
@@ -29,6 +37,7 @@ struct launch_param {
 template <typename... KArgs>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
                    typename launch_param<KArgs>::type... args) {
+  if (dry_launches()) return;
   void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {const_cast<void*>(static_cast<const void*>(&args))...};
   hipEvent_t start = nullptr, stop = nullptr;
   LaunchEventSource source = launch_event_source();

@@ -13,6 +13,7 @@ buffers, both message passes, normalisers, marginals, EM statistics — lives in
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass
 from typing import Callable, List, Optional
 
@@ -107,6 +108,9 @@ class _PlanHandle:
     def __init__(self, lib, handle):
         self.lib = lib
         self.handle = handle
+        # the flat CPT tensor whose values the plan's snapshot is known to hold (weak reference and
+        # the tensor's version counter at that time), set by ``em_step``
+        self.snapshot_of = None
 
     def __del__(self):
         if self.handle:
@@ -218,13 +222,16 @@ class HipSpaInferenceMachine(IInferenceMachine):
         store = getattr(self._nodes[0], "_store", None) if self._nodes else None
         if (store is not None and store.network is bayesian_network and store.complete
                 and store.count == len(self._nodes)):
-            self.set_cpts(store.flat)  # all CPTs already sit back to back in network order
+            known = self._owner.snapshot_of
+            if known is None or known[0]() is not store.flat or known[1] != store.flat._version:
+                self.set_cpts(store.flat)  # all CPTs already sit back to back in network order
         else:
             self.set_cpts([node.cpt for node in self._nodes])
         self.factor_graph = _FactorGraphView(bayesian_network)
         self.must_iterate: bool = True
         self.iterations_run = 0
         self._evidence_keepalive = None
+        self._evidence_to_restore = None
 
     def __del__(self):
         owner = getattr(self, "_owner", None)
@@ -238,6 +245,13 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def _stream(self):
         return ctypes.c_void_p(_stream_handle(self._device))
 
+    def _restore_evidence(self) -> None:
+        """After ``em_step`` the engine holds new parameters and no evidence; the batch's evidence is
+        entered again when something is asked of this machine afterwards."""
+        evidence, self._evidence_to_restore = self._evidence_to_restore, None
+        if evidence is not None:
+            self.enter_evidence(evidence)
+
     def set_cpts(self, cpts) -> None:
         """Snapshot CPTs into the plan: one tensor per node in network order, or one flat
         tensor holding their concatenation."""
@@ -247,8 +261,12 @@ class HipSpaInferenceMachine(IInferenceMachine):
             flat = _flatten_cpts(cpts, self._device, self._dtype)
         if flat.numel() != self._lib.bn_plan_cpt_elements(self._plan):
             raise ValueError("CPT sizes do not match the network the machine was built for")
+        self._owner.snapshot_of = None
         with torch.cuda.device(self._device):
             _native.check(self._lib.bn_set_cpts(self._plan, ctypes.c_void_p(flat.data_ptr()), self._stream()))
+        if isinstance(cpts, torch.Tensor) and flat.data_ptr() == cpts.data_ptr() and flat.numel() == cpts.numel():
+            # the caller's own buffer: the plan now holds its values as of this version
+            self._owner.snapshot_of = (weakref.ref(cpts), cpts._version)
         self._cpt_keepalive = flat
         self.must_iterate = True
 
@@ -324,6 +342,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
         return states
 
     def _iterate(self) -> None:
+        self._restore_evidence()
         callback = self._settings.callback
         tolerance = self._settings.convergence_tolerance
         self.iterations_run = 0
@@ -390,6 +409,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
     # ------------------------------------------------------------------ extensions
     def log_likelihood_tensor(self) -> torch.Tensor:
         """Log-likelihood as a one-element float64 device tensor (no host sync)."""
+        self._restore_evidence()
         out = torch.empty((1,), device=self._device, dtype=torch.float64)
         if self.must_iterate and not self._settings.callback and self._settings.convergence_tolerance is None:
             # iterations and log-likelihood in one engine call; the last iteration's messages are
@@ -433,6 +453,10 @@ class HipSpaInferenceMachine(IInferenceMachine):
         With ``evidence`` the call is ``enter_evidence(evidence)`` followed by ``em_statistics()``;
         the engine then gets both in one call and may read the evidence while it runs the first
         iteration instead of copying it first (same results, same state afterwards)."""
+        if evidence is None:
+            self._restore_evidence()
+        else:
+            self._evidence_to_restore = None
         plain = self._settings.callback is None and self._settings.convergence_tolerance is None
         if evidence is not None and not plain:
             self.enter_evidence(evidence)
@@ -469,6 +493,44 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self.must_iterate = False
         self.iterations_run = self._num_iterations
         return ll, counts
+
+    @property
+    def can_em_step(self) -> bool:
+        return self._settings.callback is None and self._settings.convergence_tolerance is None
+
+    def em_step(self, evidence: Evidence, learning_rate: Optional[float], regularization: Optional[float]):
+        """One mini-batch EM step in a single engine call: ``em_statistics(evidence)`` followed by
+        ``m_step`` with the engine's current parameters as the old ones.  Returns
+        ``(log_likelihood_tensor, new flat CPT buffer)``; the engine then already holds the new
+        parameters (a machine built next from a network that carries exactly this buffer does not
+        copy them again).  The reference's loop body, ``optimizers/em_batch_optimizer.py:37-59``."""
+        if not self.can_em_step:
+            raise RuntimeError("em_step needs plain settings (no callback, no convergence tolerance)")
+        total = self._lib.bn_plan_cpt_elements(self._plan)
+        ll = torch.empty((1,), device=self._device, dtype=torch.float64)
+        new = torch.empty((total,), device=self._device, dtype=self._dtype)
+        average = 1 if self._settings.average_log_likelihood else 0
+        rate = -1.0 if learning_rate is None else float(learning_rate)
+        gamma = float(regularization or 0.0)
+        with torch.cuda.device(self._device):
+            if isinstance(evidence, HardEvidence):
+                states = self._hard_states(evidence)
+                keep = states
+                rc = self._lib.bn_em_step(self._plan, None, ctypes.c_void_p(states.data_ptr()), evidence.on_value,
+                                          evidence.off_value, self._num_iterations, average, rate, gamma,
+                                          ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(new.data_ptr()), self._stream())
+            else:
+                keep = self._evidence_table(evidence)
+                rc = self._lib.bn_em_step(self._plan, keep[2], None, 1.0, 0.0, self._num_iterations, average, rate,
+                                          gamma, ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(new.data_ptr()),
+                                          self._stream())
+            _native.check(rc)
+        self._evidence_keepalive = keep
+        self._owner.snapshot_of = (weakref.ref(new), new._version)
+        self._evidence_to_restore = evidence
+        self.must_iterate = True
+        self.iterations_run = self._num_iterations
+        return ll, new
 
     def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],
                learning_rate: Optional[float], regularization: Optional[float]) -> torch.Tensor:
@@ -556,3 +618,13 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def unmapped_bytes(self) -> int:
         """Bytes of message arrays that exist as addresses only (no query has needed them yet)."""
         return self._lib.bn_plan_unmapped_bytes(self._plan)
+
+    @property
+    def step_graph_launches(self) -> int:
+        """How often the engine ran an ``em_statistics`` launch sequence as one captured graph."""
+        return self._lib.bn_plan_step_graph_launches(self._plan)
+
+    def enable_step_graphs(self, enabled: bool = True) -> None:
+        """Small batches replay repeated ``em_statistics`` calls as a captured graph; ``False`` makes
+        the engine launch kernel by kernel (same results)."""
+        _native.check(self._lib.bn_plan_enable_step_graphs(self._plan, 1 if enabled else 0))

@@ -44,6 +44,23 @@ class EmBatchOptimizer(IBatchOptimizer):
                 machine = self._factory(self._network)
                 deferred = cfg.deferred_logging and hasattr(machine, "log_likelihood_tensor")
                 count_sums = None
+                if (not cfg.sharded and getattr(machine, "can_em_step", False)):
+                    # the whole step in one engine call; the parameters it returns become the network's
+                    if flat_model is None:
+                        flat_model = FlatModel.of(self._network)
+                        flat_model.assign(flat_model.gather())  # nodes read one shared buffer from here on
+                        machine = self._factory(self._network)
+                    ll, flat = machine.em_step(evidence, cfg.learning_rate, cfg.regularization)
+                    flat_model.assign(flat)
+                    if not deferred:
+                        ll = ll.item()
+                    if deferred:
+                        pending.append((iteration, ll))
+                    elif self._logger:
+                        self._logger.log(epoch, iteration, ll)
+                    if self._evaluator:
+                        self._evaluator.evaluate(epoch, iteration, self._network)
+                    continue
                 if hasattr(machine, "em_statistics"):
                     # evidence, iterations, log-likelihood and expected counts in one engine call
                     ll, count_sums = machine.em_statistics(evidence)

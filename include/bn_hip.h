@@ -99,6 +99,19 @@ int64_t bn_plan_device_bytes(const bn_plan* plan);
 int64_t bn_plan_unmapped_bytes(const bn_plan* plan);
 
 /*
+ * Small batches are bound by the number of kernel launches of a call (the reference's own batch
+ * size is 100, dev_experiments/mnist/mnist.py:38), so bn_em_statistics* runs its launch sequence
+ * as one captured graph from the third call on that finds the plan in the same state with the same
+ * num_iterations and count-sum request (the second such call captures; batches of more than 16384
+ * float32 / 8192 float64 observations are launched kernel by kernel as before).  Results are
+ * bit-identical either way.  bn_plan_enable_step_graphs(plan, 0) turns this off for a plan (1 back
+ * on; BN_STEP_GRAPH=0 in the environment turns it off for the process);
+ * bn_plan_step_graph_launches counts the graph launches a plan has made.
+ */
+int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled);
+int64_t bn_plan_step_graph_launches(const bn_plan* plan);
+
+/*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
  * Replaces torch.stack(node.cpt ...) in FactorNodeGroup.__init__
  * (spa_v3/factor_graph.py:192).
@@ -226,6 +239,25 @@ int bn_em_statistics_from(bn_plan* plan, const void* const* evidence_dev, int32_
 int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, double on_value, double off_value,
                                  int32_t num_iterations, int32_t average, double* ll_out_dev, double* accum_dev,
                                  void* stream);
+
+/*
+ * One whole mini-batch EM step in a single call (EmBatchOptimizer.optimize's loop body,
+ * optimizers/em_batch_optimizer.py:37-59: a machine for the batch, enter_evidence, log_likelihood,
+ * the E-step's family marginals, _m_step):
+ *   bn_reset_messages; evidence as in bn_em_statistics_from (evidence_dev, states_dev == NULL) or
+ *   bn_em_statistics_from_states (states_dev with on_value / off_value, evidence_dev == NULL);
+ *   num_iterations iterations; *ll_out_dev = log-likelihood (mean if average); count sums into a
+ *   buffer of the plan; bn_m_step from them with the plan's current CPT snapshot as the old CPTs
+ *   (learning_rate < 0: no blending); the result becomes the plan's snapshot (as bn_set_cpts would
+ *   make it) and is written to new_cpts_dev (flat, plan dtype).
+ * Afterwards the plan is as after bn_set_cpts + bn_reset_messages: evidence has to be entered again
+ * before anything is queried.  Same kernels and results as the separate calls; the point is the
+ * number of host calls and launches per step, which is what bounds small batches (see
+ * bn_plan_enable_step_graphs: this sequence, M-step included, runs as one captured graph).
+ */
+int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
+               double off_value, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
+               double* ll_out_dev, void* new_cpts_dev, void* stream);
 
 /*
  * M-step for the whole network in one launch.  For every CPT row (last axis) of every node:

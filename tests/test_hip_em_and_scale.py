@@ -491,3 +491,111 @@ def test_message_arrays_of_fused_families_are_backed_on_first_use(name):
     ll2_lazy, c2_lazy = lazy.em_statistics(evidence)
     ll2_eager, c2_eager = eager.em_statistics(evidence)
     assert ll2_lazy.item() == ll2_eager.item() and torch.equal(c2_lazy, c2_eager)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32", "c1_docs1_f32", "c3a_784_f64"])
+def test_captured_launch_sequence_equals_kernel_by_kernel(name):
+    """Repeated statistics calls on a small batch replay one captured graph; everything they return,
+    and everything queried afterwards, is bit-identical to the kernel-by-kernel launches."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    ts = TorchSettings(device="cuda", dtype=fx.meta["dtype"])
+    network, observed, _ = fx.build(ts)
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=fx.meta["num_iterations"],
+                                           allow_loops=fx.meta["allow_loops"])
+    n = fx.meta["N"]
+    rows = [e.cuda() for e in fx.evidence_tensors()]
+    batches = [Evidence(rows, ts), Evidence([r.flip(0).contiguous() for r in rows], ts)]
+
+    def run(graphs):
+        machine = HipSpaInferenceMachine(settings, network, observed, n)
+        machine.enable_step_graphs(graphs)
+        base = machine.step_graph_launches
+        out = []
+        cpts = None
+        for step in range(7):
+            machine.reset_messages()
+            ll, counts = machine.em_statistics(batches[step % 2])
+            out += [ll.clone(), counts.clone()]
+            if step == 3:  # a query in between: the plan leaves and re-enters the state the graph was made for
+                out += machine.infer_single_nodes([observed[0], list(network.nodes)[0]])
+            if step == 4:  # new parameters
+                cpts = machine.m_step(counts, None, None, 0.05)
+                machine.set_cpts(cpts)
+        out += machine.infer_nodes_with_parents([observed[-1]])
+        out.append(machine.log_likelihood_tensor().clone())
+        launches = machine.step_graph_launches - base
+        machine.enable_step_graphs(True)
+        return out, launches
+
+    captured, launches = run(True)
+    plain, none = run(False)
+    assert none == 0 and launches >= 4, (none, launches)
+    assert len(captured) == len(plain)
+    for a, b in zip(captured, plain):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hard", [False, True])
+@pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32", "c2_docs2_f32", "c3a_784_f64"])
+def test_one_call_em_step_equals_the_separate_calls(name, hard):
+    """``em_step`` (statistics, M-step and parameter hand-over in one engine call, replayed as a
+    captured graph after the second step) against ``em_statistics`` + ``m_step`` + a new machine
+    per batch: same log-likelihoods, same parameters after every step, same answers when the machine
+    is queried after its step."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    fx = Fixture(name)
+    ts = TorchSettings(device="cuda", dtype=fx.meta["dtype"])
+    settings = SpaInferenceMachineSettings(ts, True, num_iterations=fx.meta["num_iterations"],
+                                           allow_loops=fx.meta["allow_loops"])
+    n = fx.meta["N"]
+
+    def batches_for(observed):
+        if hard:
+            gen = torch.Generator().manual_seed(5)
+            out = []
+            for _ in range(2):
+                states = torch.stack([torch.randint(0, o.num_states, (n,), generator=gen) for o in observed])
+                out.append(HardEvidence(states.cuda(), [o.num_states for o in observed], ts, 1.0 - 1e-6, 1e-6))
+            return out
+        rows = [e.cuda() for e in fx.evidence_tensors()]
+        return [Evidence(rows, ts), Evidence([r.flip(0).contiguous() for r in rows], ts)]
+
+    def run(one_call):
+        network, observed, _ = fx.build(ts)
+        batches = batches_for(observed)
+        model = FlatModel.of(network)
+        model.assign(model.gather())
+        trace = []
+        for step in range(6):
+            machine = HipSpaInferenceMachine(settings, network, observed, n)
+            if one_call:
+                ll, new = machine.em_step(batches[step % 2], 0.2, 0.01)
+            else:
+                ll, counts = machine.em_statistics(batches[step % 2])
+                new = machine.m_step(counts, model.gather(), 0.2, 0.01)
+            trace += [ll.clone(), new.clone()]
+            if step == 3:
+                # asked after its step, a machine answers for the batch's evidence under the new parameters
+                if not one_call:
+                    model.assign(new)
+                    machine = HipSpaInferenceMachine(settings, network, observed, n)
+                    machine.enter_evidence(batches[step % 2])
+                trace += machine.infer_single_nodes([list(network.nodes)[0], observed[0]])
+                trace.append(machine.log_likelihood_tensor().clone())
+            model.assign(new)
+            del machine
+        return trace
+
+    one, separate = run(True), run(False)
+    assert len(one) == len(separate)
+    for a, b in zip(one, separate):
+        assert torch.equal(a, b)

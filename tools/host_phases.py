@@ -21,8 +21,8 @@ for i in range(steps):
         for k in acc: acc[k] = 0.0
         torch.cuda.synchronize(); t_all = time.perf_counter()
     t0 = time.perf_counter(); machine = HipSpaInferenceMachine(settings, network, ys, n)
-    t1 = time.perf_counter(); machine.enter_evidence(ev[i % 2])
-    t2 = time.perf_counter(); ll, counts = machine.em_statistics()
+    t1 = time.perf_counter()
+    t2 = time.perf_counter(); ll, counts = machine.em_statistics(ev[i % 2])
     t3 = time.perf_counter(); flat = model.gather()
     t4 = time.perf_counter(); new = machine.m_step(counts, flat, 0.1, 0.01)
     t5 = time.perf_counter(); model.assign(new)
