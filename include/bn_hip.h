@@ -99,14 +99,15 @@ int64_t bn_plan_device_bytes(const bn_plan* plan);
 int64_t bn_plan_unmapped_bytes(const bn_plan* plan);
 
 /*
- * Small batches are bound by the number of kernel launches of a call (the reference's own batch
- * size is 100, dev_experiments/mnist/mnist.py:38), so bn_em_statistics* runs its launch sequence
- * as one captured graph from the third call on that finds the plan in the same state with the same
- * num_iterations and count-sum request (the second such call captures; batches of more than 16384
- * float32 / 8192 float64 observations are launched kernel by kernel as before).  Results are
- * bit-identical either way.  bn_plan_enable_step_graphs(plan, 0) turns this off for a plan (1 back
- * on; BN_STEP_GRAPH=0 in the environment turns it off for the process);
- * bn_plan_step_graph_launches counts the graph launches a plan has made.
+ * Small batches are bound by the chain of dependent kernel launches of a call (the reference's own
+ * batch size is 100, dev_experiments/mnist/mnist.py:38).  On request, bn_em_statistics* and
+ * bn_em_step run their launch sequence as one captured graph from the third call on that finds the
+ * plan in the same state with the same arguments (the second such call captures; batches of more
+ * than 16384 float32 / 8192 float64 observations are always launched kernel by kernel).  Results are
+ * bit-identical either way.  bn_plan_enable_step_graphs(plan, 1) switches it on for a plan, 0 off
+ * (the default, unless BN_STEP_GRAPH=1 is in the environment when the plan is created: replaying
+ * measured slightly slower than launching on the runtime this was built against; BN_STEP_GRAPH=0
+ * forbids it for the process); bn_plan_step_graph_launches counts the graph launches a plan has made.
  */
 int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled);
 int64_t bn_plan_step_graph_launches(const bn_plan* plan);

@@ -529,7 +529,7 @@ def test_captured_launch_sequence_equals_kernel_by_kernel(name):
         out += machine.infer_nodes_with_parents([observed[-1]])
         out.append(machine.log_likelihood_tensor().clone())
         launches = machine.step_graph_launches - base
-        machine.enable_step_graphs(True)
+        machine.enable_step_graphs(False)  # the plan goes back to the pool as plans are made
         return out, launches
 
     captured, launches = run(True)
@@ -540,9 +540,10 @@ def test_captured_launch_sequence_equals_kernel_by_kernel(name):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
 @pytest.mark.parametrize("hard", [False, True])
 @pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32", "c2_docs2_f32", "c3a_784_f64"])
-def test_one_call_em_step_equals_the_separate_calls(name, hard):
+def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
     """``em_step`` (statistics, M-step and parameter hand-over in one engine call, replayed as a
     captured graph after the second step) against ``em_statistics`` + ``m_step`` + a new machine
     per batch: same log-likelihoods, same parameters after every step, same answers when the machine
@@ -577,6 +578,7 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard):
         trace = []
         for step in range(6):
             machine = HipSpaInferenceMachine(settings, network, observed, n)
+            machine.enable_step_graphs(graphs and one_call)
             if one_call:
                 ll, new = machine.em_step(batches[step % 2], 0.2, 0.01)
             else:
@@ -592,6 +594,7 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard):
                 trace += machine.infer_single_nodes([list(network.nodes)[0], observed[0]])
                 trace.append(machine.log_likelihood_tensor().clone())
             model.assign(new)
+            machine.enable_step_graphs(False)
             del machine
         return trace
 
