@@ -582,6 +582,25 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
     return launch_ok() ? 1 : -1;
   }
   if constexpr (!std::is_same<T, float>::value) {
+    // 32 or 64 states in float64: states split over the eight waves of a block (one tile of 128 observations)
+    if ((g.num_states == 32 || g.num_states == 64) && g.num_inputs >= 1 && g.num_inputs <= 4) {
+      double* arena = arena_t;
+      const int32_t K = (int32_t)g.nodes.size();
+      const dim3 blocks((uint32_t)((int64_t)K * p.ntiles));
+      const bool wide64 = g.num_states == 64;
+      switch (g.num_inputs) {
+#define X(IV)                                                                                                  \
+  case IV:                                                                                                     \
+    if (wide64)                                                                                                \
+      launch(variable_split_f64<IV, 8>, blocks, dim3(512), 0, s, arena, g.d_in, g.d_out, g.d_c, K, p.ntiles, fresh); \
+    else                                                                                                       \
+      launch(variable_split_f64<IV, 4>, blocks, dim3(512), 0, s, arena, g.d_in, g.d_out, g.d_c, K, p.ntiles, fresh);  \
+    break;
+        X(1) X(2) X(3) X(4)
+#undef X
+      }
+      return launch_ok() ? 1 : -1;
+    }
     return 0;
   } else {
     float* arena = arena_t;
@@ -811,6 +830,14 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
           launch(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
           return launch_ok() ? 1 : -1;
         }
+      } else {
+        if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
+          const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
+          FactorFn<double> dense = d0 == 64 ? (sv == 64 ? factor_p1_mfma_f64<64, 64> : factor_p1_mfma_f64<64, 32>)
+                                            : (sv == 64 ? factor_p1_mfma_f64<32, 64> : factor_p1_mfma_f64<32, 32>);
+          launch(dense, grid, dim3(256), 0, s, arena, cpts, g.d_in, g.d_out, g.d_cpt, K, p.ntiles);
+          return launch_ok() ? 1 : -1;
+        }
       }
       FactorFn<T> fn = factor_p1_lookup<T>(d0, sv);
       if (!fn) return 0;
@@ -840,6 +867,14 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena, int32_t nchunks, dou
       if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
         EmP1Fn dense = d0 == 64 ? (sv == 64 ? em_p1_mfma<64, 64> : em_p1_mfma<64, 32>)
                                 : (sv == 64 ? em_p1_mfma<32, 64> : em_p1_mfma<32, 32>);
+        launch(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
+               p.ntiles, nchunks, partial);
+        return launch_ok() ? 1 : -1;
+      }
+    } else {
+      if ((d0 == 32 || d0 == 64) && (sv == 32 || sv == 64)) {
+        EmFn<double> dense = d0 == 64 ? (sv == 64 ? em_p1_mfma_f64<64, 64> : em_p1_mfma_f64<64, 32>)
+                                      : (sv == 64 ? em_p1_mfma_f64<32, 64> : em_p1_mfma_f64<32, 32>);
         launch(dense, dim3((uint32_t)((int64_t)K * nchunks)), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N,
                p.ntiles, nchunks, partial);
         return launch_ok() ? 1 : -1;

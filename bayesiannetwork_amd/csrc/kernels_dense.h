@@ -323,6 +323,343 @@ __global__ void __launch_bounds__(512) variable_split_fast(float* __restrict__ a
   }
 }
 
+// =================================================================================
+// float64 plans (the element type of the reference's own experiment scripts,
+// dev_experiments/mnist/mnist.py:32): the same three kernels on v_mfma_f64_16x16x4_f64 and on
+// mantissa / exponent products.  A tile holds 128 observations.
+// =================================================================================
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int32_t kTile64 = 128;
+
+// Factor pass, one parent, D0, S in {32, 64}, float64.  One workgroup (4 waves) per (node, tile);
+// wave w owns observations [32 w, 32 w + 32) as two 16-wide column tiles.
+//   A operand  lane l holds W[i = l & 15][k = l >> 4]   (CPT or its transpose, from LDS, pitch 65)
+//   B operand  lane l holds MSG^T[k = l >> 4][j = l & 15]: 16 lanes read 128 consecutive bytes
+//   D          register r of lane l is row 4 r + (l >> 4), column l & 15 (tools/ubench/mfma_f64_layout.hip)
+template <int D0, int S>
+__global__ void __launch_bounds__(256) factor_p1_mfma_f64(double* __restrict__ arena, const double* __restrict__ cpts,
+                                                         const int64_t* __restrict__ in_off,
+                                                         const int64_t* __restrict__ out_off,
+                                                         const int64_t* __restrict__ cpt_off, int32_t K,
+                                                         int64_t ntiles) {
+  __shared__ double w_lds[D0 * kCptPitch];
+  const int64_t item = blockIdx.x;
+  const int32_t k = (int32_t)(item / ntiles);
+  const int64_t t = item % ntiles;
+  if (k >= K) return;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t kq = lane >> 4, col = lane & 15;
+
+  const double* cpt = cpts + cpt_off[k];
+  for (int32_t e = threadIdx.x; e < D0 * S; e += 256) w_lds[(e / S) * kCptPitch + (e % S)] = cpt[e];
+  __syncthreads();
+
+  const double* in_par = arena + in_off[2 * k] + t * D0 * kTile64 + wave * 32;
+  const double* in_own = arena + in_off[2 * k + 1] + t * S * kTile64 + wave * 32;
+  double* out_par = arena + out_off[2 * k] + t * D0 * kTile64 + wave * 32;
+  double* out_own = arena + out_off[2 * k + 1] + t * S * kTile64 + wave * 32;
+
+  // ---- to own variable: out_own^T[b][n] = sum_a cpt[a][b] * in_par^T[a][n]
+  {
+    f64x4 acc[S / 16][2];
+#pragma unroll
+    for (int32_t it = 0; it < S / 16; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) acc[it][jt][r] = 0.0;
+#pragma unroll
+    for (int32_t ks = 0; ks < D0 / 4; ++ks) {
+      const int32_t a = 4 * ks + kq;
+      double bfrag[2];
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt) bfrag[jt] = in_par[(int64_t)a * kTile64 + 16 * jt + col];
+#pragma unroll
+      for (int32_t it = 0; it < S / 16; ++it) {
+        const double afrag = w_lds[a * kCptPitch + 16 * it + col];  // W[i=b][k=a] = cpt[a][b]
+#pragma unroll
+        for (int32_t jt = 0; jt < 2; ++jt)
+          acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int32_t it = 0; it < S / 16; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r)
+          out_own[(int64_t)(16 * it + 4 * r + kq) * kTile64 + 16 * jt + col] = acc[it][jt][r];
+  }
+  // ---- to parent: out_par^T[a][n] = sum_b cpt[a][b] * in_own^T[b][n]
+  {
+    f64x4 acc[D0 / 16][2];
+#pragma unroll
+    for (int32_t it = 0; it < D0 / 16; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) acc[it][jt][r] = 0.0;
+#pragma unroll
+    for (int32_t ks = 0; ks < S / 4; ++ks) {
+      const int32_t b = 4 * ks + kq;
+      double bfrag[2];
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt) bfrag[jt] = in_own[(int64_t)b * kTile64 + 16 * jt + col];
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 16; ++it) {
+        const double afrag = w_lds[(16 * it + col) * kCptPitch + b];  // W[i=a][k=b] = cpt[a][b]
+#pragma unroll
+        for (int32_t jt = 0; jt < 2; ++jt)
+          acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int32_t it = 0; it < D0 / 16; ++it)
+#pragma unroll
+      for (int32_t jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r)
+          out_par[(int64_t)(16 * it + 4 * r + kq) * kTile64 + 16 * jt + col] = acc[it][jt][r];
+  }
+}
+
+// EM count matrix of the same families in float64: stat[a][b] = sum_n in_par[n][a] * in_own[n][b].
+// One workgroup per (node, chunk of tiles); 32 observations of both messages are staged in LDS
+// per step (pitch 33), each wave owns a quarter of the 16x16 output tiles.
+template <int D0, int S>
+__global__ void __launch_bounds__(256) em_p1_mfma_f64(const double* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                     const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
+                                                     int64_t ntiles, int32_t nchunks, double* __restrict__ partial) {
+  constexpr int32_t kPitch = 33;
+  __shared__ double par_lds[D0 * kPitch];
+  __shared__ double own_lds[S * kPitch];
+  const int32_t k = blockIdx.x / nchunks;
+  const int32_t chunk = blockIdx.x % nchunks;
+  if (k >= K) return;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t kq = lane >> 4, col = lane & 15;
+  constexpr int32_t kTilesOut = (D0 / 16) * (S / 16);  // 16x16 output tiles
+  constexpr int32_t kPerWave = kTilesOut / 4;
+  static_assert(kTilesOut % 4 == 0, "output tiles split evenly over four waves");
+
+  const double* in_par = arena + in_off[2 * k];
+  const double* in_own = arena + in_off[2 * k + 1];
+  const int64_t per = (ntiles + nchunks - 1) / nchunks;
+  const int64_t t0 = chunk * per;
+  const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
+
+  f64x4 acc[kPerWave];
+#pragma unroll
+  for (int32_t q = 0; q < kPerWave; ++q)
+#pragma unroll
+    for (int32_t r = 0; r < 4; ++r) acc[q][r] = 0.0;
+
+  for (int64_t t = t0; t < t1; ++t) {
+    for (int32_t part = 0; part < kTile64 / 32; ++part) {
+      const int64_t n0 = t * kTile64 + part * 32;
+      if (n0 >= N) break;
+      __syncthreads();
+      // stage [rows][32 observations]; thread -> (row, 2 observations); padding observations as zero
+      for (int32_t e = threadIdx.x; e < D0 * 16; e += 256) {
+        const int32_t row = e >> 4, c2 = (e & 15) * 2;
+        const double2 x = *reinterpret_cast<const double2*>(in_par + (t * D0 + row) * kTile64 + part * 32 + c2);
+        par_lds[row * kPitch + c2] = n0 + c2 < N ? x.x : 0.0;
+        par_lds[row * kPitch + c2 + 1] = n0 + c2 + 1 < N ? x.y : 0.0;
+      }
+      for (int32_t e = threadIdx.x; e < S * 16; e += 256) {
+        const int32_t row = e >> 4, c2 = (e & 15) * 2;
+        const double2 x = *reinterpret_cast<const double2*>(in_own + (t * S + row) * kTile64 + part * 32 + c2);
+        own_lds[row * kPitch + c2] = x.x;
+        own_lds[row * kPitch + c2 + 1] = x.y;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int32_t q = 0; q < kPerWave; ++q) {
+        const int32_t tile = wave * kPerWave + q;
+        const int32_t it = tile / (S / 16), jt = tile % (S / 16);
+#pragma unroll
+        for (int32_t ks = 0; ks < 8; ++ks) {
+          const int32_t n = 4 * ks + kq;
+          const double afrag = par_lds[(16 * it + col) * kPitch + n];  // A[i=a][k=n]
+          const double bfrag = own_lds[(16 * jt + col) * kPitch + n];  // B[k=n][j=b]
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag, acc[q], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int32_t q = 0; q < kPerWave; ++q) {
+    const int32_t tile = wave * kPerWave + q;
+    const int32_t it = tile / (S / 16), jt = tile % (S / 16);
+#pragma unroll
+    for (int32_t r = 0; r < 4; ++r) {
+      const int32_t a = 16 * it + 4 * r + kq, b = 16 * jt + col;
+      partial[(cpt_off[k] + (int64_t)a * S + b) * nchunks + chunk] = acc[q][r];
+    }
+  }
+}
+
+// Variable pass for nodes with 8*SQ states and a small fan-in I (<= 4) in float64: as
+// variable_split_fast, a block of eight waves owns (node, tile of 128 observations) and wave w keeps
+// states [w*SQ, (w+1)*SQ) of all inputs in registers.  Products of doubles can leave the double
+// range (the reference works on logarithms here, factor_graph.py:114-138), so every product is a
+// mantissa with its exponent apart, and every sum over the states is taken relative to the
+// largest exponent among its terms: first the waves agree on those largest exponents, then on the
+// sums.   grid.x = K * ntiles, block = 512
+template <int I, int SQ>
+__global__ void __launch_bounds__(512) variable_split_f64(double* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                         const int64_t* __restrict__ out_off,
+                                                         const int64_t* __restrict__ c_off, int32_t K,
+                                                         int64_t ntiles, int32_t fresh) {
+  constexpr int32_t NW = 8, S = NW * SQ;
+  __shared__ int32_t top_lds[NW][I + 1][2][64];
+  __shared__ double sum_lds[NW][I + 1][2][64];
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t item = blockIdx.x;  // (node, tile)
+  const int32_t k = (int32_t)(item / ntiles);
+  const int64_t t = item % ntiles;
+  const int32_t col = lane * 2;
+  const double uniform = 1.0 / (double)S;
+
+  double2 in[I][SQ];
+  double* dst[I];
+#pragma unroll
+  for (int32_t i = 0; i < I; ++i) {
+    const int64_t o = out_off[(int64_t)k * I + i];
+    dst[i] = o != kNoArray ? arena + o + (t * S + wave * SQ) * kTile64 + col : nullptr;
+    const bool skip = fresh && o != kNoArray;  // a message slot that still holds its initial uniform value
+    const double* src = arena + in_off[(int64_t)k * I + i] + (t * S + wave * SQ) * kTile64 + col;
+#pragma unroll
+    for (int32_t q = 0; q < SQ; ++q)
+      in[i][q] = skip ? make_double2(uniform, uniform) : *reinterpret_cast<const double2*>(src + (int64_t)q * kTile64);
+  }
+  // Term i < I of state q: the leave-one-out product prod_{j != i} in_j; term I: the full product.
+  // Both as mantissa * 2^exponent (exponent kDeadExponent for an exact zero).
+  auto terms = [&](int32_t q, int32_t v, double (&m)[I + 1], int32_t (&e)[I + 1]) {
+    double fm[I];
+    int32_t fe[I];
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) {
+      int de = 0;
+      fm[i] = frexp(v ? in[i][q].y : in[i][q].x, &de);
+      fe[i] = de;
+    }
+    double pre = 1.0, suf = 1.0;
+    int32_t pre_e = 0, suf_e = 0;
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i) {
+      m[i] = pre;
+      e[i] = pre_e;
+      pre *= fm[i];
+      pre_e += fe[i];
+    }
+    m[I] = pre;
+    e[I] = pre_e;
+#pragma unroll
+    for (int32_t i = I - 1; i >= 0; --i) {
+      m[i] *= suf;
+      e[i] += suf_e;
+      suf *= fm[i];
+      suf_e += fe[i];
+    }
+#pragma unroll
+    for (int32_t i = 0; i <= I; ++i) {
+      int de = 0;
+      m[i] = frexp(m[i], &de);  // at most four mantissas multiplied: far from the range's end
+      e[i] = m[i] == 0.0 ? kDeadExponent : e[i] + de;
+    }
+  };
+  // 1. largest exponent of every term kind over all states
+  int32_t top[I + 1][2];
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i) top[i][0] = top[i][1] = kDeadExponent;
+#pragma unroll
+  for (int32_t q = 0; q < SQ; ++q)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double m[I + 1];
+      int32_t e[I + 1];
+      terms(q, v, m, e);
+#pragma unroll
+      for (int32_t i = 0; i <= I; ++i) top[i][v] = e[i] > top[i][v] ? e[i] : top[i][v];
+    }
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) top_lds[wave][i][v][lane] = top[i][v];
+  __syncthreads();
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      int32_t x = kDeadExponent;
+#pragma unroll
+      for (int32_t w = 0; w < NW; ++w) x = top_lds[w][i][v][lane] > x ? top_lds[w][i][v][lane] : x;
+      top[i][v] = x;
+    }
+  // 2. sums over the states relative to those exponents
+  double sums[I + 1][2];
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i) sums[i][0] = sums[i][1] = 0.0;
+#pragma unroll
+  for (int32_t q = 0; q < SQ; ++q)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double m[I + 1];
+      int32_t e[I + 1];
+      terms(q, v, m, e);
+#pragma unroll
+      for (int32_t i = 0; i <= I; ++i) sums[i][v] += ldexp(m[i], clamp_shift(e[i] - top[i][v]));
+    }
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) sum_lds[wave][i][v][lane] = sums[i][v];
+  __syncthreads();
+#pragma unroll
+  for (int32_t i = 0; i <= I; ++i)
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double x = 0.0;
+#pragma unroll
+      for (int32_t w = 0; w < NW; ++w) x += sum_lds[w][i][v][lane];
+      sums[i][v] = x;
+    }
+  if (wave == 0) {
+    double2 c;
+    c.x = (double)top[I][0] * 0.6931471805599453 + log(sums[I][0]);
+    c.y = (double)top[I][1] * 0.6931471805599453 + log(sums[I][1]);
+    *reinterpret_cast<double2*>(arena + c_off[k] + t * kTile64 + col) = c;
+  }
+  // 3. outgoing messages: leave-one-out product over its sum; the message to the local factor
+  //    (slot I - 1) is normalised by the full product's sum instead
+#pragma unroll
+  for (int32_t v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int32_t i = 0; i < I - 1; ++i) sums[i][v] = 1.0 / sums[i][v];
+    sums[I - 1][v] = 1.0 / sums[I][v];
+    top[I - 1][v] = top[I][v];
+  }
+#pragma unroll
+  for (int32_t q = 0; q < SQ; ++q) {
+    double2 out[I];
+#pragma unroll
+    for (int32_t v = 0; v < 2; ++v) {
+      double m[I + 1];
+      int32_t e[I + 1];
+      terms(q, v, m, e);
+#pragma unroll
+      for (int32_t i = 0; i < I; ++i) {
+        const double o = ldexp(m[i], clamp_shift(e[i] - top[i][v])) * sums[i][v];
+        if (v) out[i].y = o; else out[i].x = o;
+      }
+    }
+#pragma unroll
+    for (int32_t i = 0; i < I; ++i)
+      if (dst[i]) *reinterpret_cast<double2*>(dst[i] + (int64_t)q * kTile64) = out[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Variable pass for nodes with many states and a small fan-in I (<= 4): one wave per
 // (node, tile), four observations per lane, states streamed one at a time (products are per

@@ -238,6 +238,43 @@ def cpu_baseline(model: str, n: int, iters, warmup: int = 2, steps: int = 5):
     return out
 
 
+def secondary_em_step(ts, device, model, n, steps, warmup):
+    """EM-step throughput of another workload on this GPU (resident evidence, same optimizer
+    settings as the headline run): one dict for the ``secondary`` list."""
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers import EmBatchOptimizer, EmBatchOptimizerSettings, OptimizerLogger
+
+    iters = 10 if model == "c3b" else None
+    if model == "c5":
+        network, ys = build_deep_tree(ts)
+        batches = [one_hot_evidence(ts, n, ys, 1 + b, device) for b in range(2)]
+    else:
+        network, ys = build_model(ts, model)
+        batches = [synthetic_evidence(ts, n, len(ys), 1 + b, device) for b in range(2)]
+    settings = SpaInferenceMachineSettings(ts, True, num_iterations=iters, allow_loops=model == "c3b")
+
+    def factory(net):
+        return HipSpaInferenceMachine(settings, net, ys, n)
+
+    def run(count):
+        opt = EmBatchOptimizer(network, factory,
+                               EmBatchOptimizerSettings(learning_rate=0.1, num_epochs=1, regularization=0.01,
+                                                        deferred_logging=True), OptimizerLogger())
+        opt.optimize(_Batches([batches[i % 2] for i in range(count)], n * count))
+
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_used = factory(network).num_iterations
+    workload = {"c3b": "Q(10)->F1,F2(2)->784xY(2|F1,F2) loopy model",
+                "c5": "depth-6 binary tree of 64-state hidden nodes + 32 observed 64-state leaves"}[model]
+    return dict(workload=f"{workload}, EM step (T={t_used})", batch=n, steps=steps, warmup=warmup,
+                value=n * steps / elapsed, unit="samples/s", ms_per_step=elapsed / steps * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,6 +289,7 @@ def main():
                          "resident-uint8: in HBM as uint8 state indices (HardEvidence).  host-*: batches start in "
                          "host memory every step and cross PCIe through PrefetchingLoader (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="leave out the loopy and deep-tree EM steps")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -274,6 +312,7 @@ def main():
 
     ts = TorchSettings(device="cuda", dtype=args.dtype)
     device = torch.device("cuda", local_rank)
+    default_size = args.batch is None
     n = args.batch or (131072 if args.model == "c5" else 60000)
     iters = 10 if args.model == "c3b" else None
     # two distinct resident batches, alternated, so no step re-reads the evidence it just used
@@ -435,6 +474,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.model != "c5":
             out["cpu_baseline"] = cpu_baseline(args.model, 7500, iters)
+        if world == 1 and not args.no_secondary and args.model == "c3a" and default_size:
+            # the other two EM workloads of the config list, a few steps each, same optimizer settings
+            del machine
+            out["secondary"] = [secondary_em_step(ts, device, "c3b", 60000, steps=10, warmup=3),
+                                secondary_em_step(ts, device, "c5", 131072, steps=2, warmup=1)]
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

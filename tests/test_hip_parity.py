@@ -300,6 +300,62 @@ def test_products_that_leave_the_floating_point_range(num_children, dtype, tiny)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("states", [32, 64])
+@pytest.mark.parametrize("dtype,tiny", [("float64", 1e-120), ("float32", 1e-30)])
+def test_many_state_products_that_leave_the_floating_point_range(states, dtype, tiny):
+    """The same for many-state nodes (the split-state variable kernel and the matrix-core factor
+    kernels): a root with three children, every child's CPT puts `tiny` on the evidence it gets, so
+    the root's product of three messages is tiny^3 in every state."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+    from oracle.spa_oracle import SpaOracle
+
+    n = 3
+    gen = torch.Generator().manual_seed(states)
+    prior = torch.rand((states,), generator=gen, dtype=torch.float64) + 0.1
+    prior = prior / prior.sum()
+    # child CPT rows: `tiny` (times a row-dependent factor) on state 0, the rest spread over the others
+    scale = 1.0 + torch.arange(states, dtype=torch.float64) / states
+    cpt = torch.rand((states, states), generator=gen, dtype=torch.float64) + 0.1
+    cpt[:, 0] = 0.0
+    cpt = cpt / cpt.sum(-1, keepdim=True)
+    cpt = cpt * (1.0 - (tiny * scale).unsqueeze(1))
+    cpt[:, 0] = tiny * scale
+
+    def build(device):
+        ts = TorchSettings(device=device, dtype=dtype)
+        q = Node(prior.to(ts.dtype).to(ts.device), name="Q")
+        ys = [Node(cpt.to(ts.dtype).to(ts.device), name=f"Y{i}") for i in range(3)]
+        builder = BayesianNetworkBuilder().add_node(q)
+        for y in ys:
+            builder.add_node(y, parents=q)
+        row = torch.full((states,), float(tiny), dtype=ts.dtype)
+        row[0] = 1.0
+        rows = [row.repeat((n, 1)) for _ in ys]
+        return ts, builder.build(), q, ys, rows
+
+    ts, network, q, ys, rows = build("cuda")
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, ys, n)
+    machine.enter_evidence(Evidence([r.to("cuda") for r in rows], ts))
+    _, network_cpu, q_cpu, ys_cpu, _ = build("cpu")
+    for a, b in zip(network_cpu.nodes, network.nodes):
+        a.cpt = b.cpt.detach().cpu()
+    oracle = SpaOracle(network_cpu, ys_cpu, n, dtype=ts.dtype)
+    oracle.enter_evidence(rows)
+
+    tol = 1e-9 if dtype == "float64" else 1e-5
+    ll = machine.log_likelihood()
+    want_ll = oracle.log_likelihood(False)
+    assert np.isfinite(ll) and abs(ll - want_ll) <= tol * abs(want_ll)
+    nodes = list(network.nodes)
+    for j, got in enumerate(machine.infer_single_nodes(nodes)):
+        assert not got.isnan().any(), nodes[j].name
+        np.testing.assert_allclose(got.cpu().double().numpy(), oracle.infer_single(j).double().numpy(), rtol=tol, atol=1e-12)
+
+
+@pytest.mark.gpu
 def test_c_abi_from_plain_cpp():
     """examples/c_abi_demo (built by `make demo`): the docs-1 network through the C ABI from C++ with
     hipMalloc'ed buffers, no Python or torch in the process.  It checks the documented posteriors
