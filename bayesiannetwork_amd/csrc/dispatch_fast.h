@@ -325,7 +325,7 @@ inline int prepare_fast(Plan& p) {
     // waves leaves a quarter of the partials for the combine to read.  One-parent groups only (the
     // loop launches of two-parent groups have no such mode).
     bool share = w.fused_fgroup >= 0 && p.ntiles * leaf_parts(p) <= env_share_max() && chunks >= 2 * kWavesPerBlock;
-    for (int32_t fi : w.fused_fgroups) share = share && st.fused[fi].wide_index2 < 0;
+    for (int32_t fi : w.fused_fgroups) share = share && st.fused[fi].wide_index2 < 0 && p.fgroups[fi].dims[1] == 2;
     if (share) chunks /= kWavesPerBlock;
     // the leaf-family kernel keeps a chunk's exponents in 16 bits
     if (w.fused_fgroup >= 0) chunks = std::max(chunks, (n + kLeafMaxChunkLen - 1) / kLeafMaxChunkLen);

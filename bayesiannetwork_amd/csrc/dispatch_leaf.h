@@ -35,8 +35,13 @@ struct LeafLoopKernel {
 };
 
 template <typename T, int D0, int OUT, int STATE>
-inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s) {
+inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s, bool split) {
   constexpr bool kFromCaller = STATE == kLoopIngest;
+  // blocks that share a chunk: instantiated for two-state leaves
+  if (split)
+    return s == 2 ? LeafLoopKernel<T>{leaf_loop_p1<T, D0, 2, OUT, STATE, true>,
+                                      (size_t)kWavesPerBlock * LeafRing<T, 2, kFromCaller>::kWaveBytes}
+                  : LeafLoopKernel<T>{};
   switch (s) {
 #define X(SV)                                                                                       \
   case SV:                                                                                          \
@@ -51,11 +56,11 @@ inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s) {
 }
 
 template <typename T, int OUT, int STATE>
-inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s) {
+inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s, bool split) {
   switch (d0) {
 #define X(DV) \
   case DV:    \
-    return leaf_loop_for_s<T, DV, OUT, STATE>(s);
+    return leaf_loop_for_s<T, DV, OUT, STATE>(s, split);
     BN_SMALL_DIMS(X)
 #undef X
   }
@@ -112,7 +117,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     switch (loop_out * 8 + from) {
 #define X(OUT, FROM)                                                      \
   case OUT * 8 + FROM:                                                    \
-    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1]);             \
+    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1], fam.split > 1); \
     break;
       X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
       X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates)

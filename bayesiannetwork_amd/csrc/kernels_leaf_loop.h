@@ -72,7 +72,10 @@ struct LeafRing {
   static constexpr int32_t kWaveBytes = kDepth * kSlotBytes;
 };
 
-template <typename T, int D0, int S, int OUT, int STATE>
+// SPLIT: the waves of a block share one (chunk, tile, part) work item, each taking a quarter of the
+// chunk's families (LeafFamilyArgs::split; an instantiation of its own so that the merge of the
+// quarters costs the ordinary launches no registers).
+template <typename T, int D0, int S, int OUT, int STATE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const T* __restrict__ cpts,
                                                    LeafFamilyArgs<T> a) {
   constexpr int32_t V = 2;
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   extern __shared__ __align__(16) unsigned char ring_raw[];
 
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const bool split = a.split > 1;  // the block's waves share one work item (uniform over the block)
+  constexpr bool split = SPLIT;  // the block's waves share one work item
   int64_t w = split ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (w >= (int64_t)a.chunks * a.ntiles * kParts) return;
   const int32_t part = (int32_t)(w % kParts);
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
 #pragma unroll
     for (int32_t j = 0; j < E; ++j) cpt_cur[j] = cpt_nxt[j];
   }
-  if (split) {
+  if constexpr (SPLIT) {
     // the four quarters' products meet in wave 0 (every factor brought to [0.5, 1) first)
     double* mm = reinterpret_cast<double*>(ring_raw + kWavesPerBlock * Ring::kWaveBytes);
     constexpr int32_t kDoubles = D0 * V + 2 * V, kInts = D0 * V + 2 * V;

@@ -35,9 +35,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-_KERNEL_STEMS = {"leaf_family": "bn::leaf_family_p", "factor_pass": "bn::factor_p", "em_counts": "bn::em_p",
-                 "variable_pass": "bn::variable_small_fast", "wide_combine": "bn::wide_combine_fast",
-                 "evidence_scatter": "bn::evidence_scatter", "log_likelihood": "bn::ll_partial"}
+# profile label -> kernel-name stems it covers (a label can stand for several kernels: the loop launches of
+# the leaf families run on leaf_loop_p1, their full / reduce launches on leaf_family_p1)
+_KERNEL_STEMS = {"leaf_family": ("bn::leaf_family_p", "bn::leaf_loop_p"), "factor_pass": ("bn::factor_p",),
+                 "em_counts": ("bn::em_p",), "variable_pass": ("bn::variable_small_fast",),
+                 "wide_combine": ("bn::wide_combine_fast", "bn::wide_combine_states"),
+                 "evidence_scatter": ("bn::evidence_scatter",), "log_likelihood": ("bn::ll_partial",)}
 
 
 def _latest_profile(suffix: str):
@@ -59,13 +62,13 @@ def pmc_counters(kernel_label: str, model: str = "c3a"):
     (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE passes; tools/pmc_valu.sh: SQ_ACTIVE_INST_VALU
     against GRBM_GUI_ACTIVE).  A label can cover several instantiations (loop / reduce modes): the
     launch-weighted mean.  None where no summary covers the kernel."""
-    stem = _KERNEL_STEMS.get(kernel_label.split("[")[0])
-    if model != "c3a" or stem is None:  # the committed passes ran the default (784-leaf) command
+    stems = _KERNEL_STEMS.get(kernel_label.split("[")[0])
+    if model != "c3a" or stems is None:  # the committed passes ran the default (784-leaf) command
         return None, None
     out = []
     for suffix, key in (("pmc_traffic.json", "hbm_bytes_per_launch"), ("pmc_valu.json", "valu_busy")):
         path = _latest_profile(suffix)
-        hits = [v for k, v in json.load(open(path)).items() if k.startswith(stem)] if path else []
+        hits = [v for k, v in json.load(open(path)).items() if k.startswith(stems)] if path else []
         hits = [h for h in hits if h.get(key) is not None]
         out.append(sum(h[key] * h["launches"] for h in hits) / sum(h["launches"] for h in hits) if hits else None)
     return out[0], out[1]

@@ -46,6 +46,19 @@ for name, values in fetch.items():
         known = 784 * 60160 * 8 + 10 * 60160 * 8
         LEAF_FACTOR = known / (1024.0 * sum(values) / len(values))
         print(f"leaf-family fetch calibration: x{LEAF_FACTOR:.3f}")
+# The loop launches (leaf_loop_p1<T, D0, S, OUT, STATE>) bring the evidence in with 16-byte-per-lane
+# LDS-DMA loads and read the parent product and the chunk state with 16-byte loads: the doubling
+# is expected to apply.  Checked on the instantiation whose reads are known exactly at the default
+# bench geometry (OUT 0, STATE 0: evidence + 10 doubles of the parent product per observation + 8
+# chunks x (8 + 4) bytes of chunk state per observation).
+LOOP = re.compile(r"leaf_loop_p1<(?:float|double), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>")
+LOOP_FACTOR = 2.0
+for name, values in fetch.items():
+    m = LOOP.search(name)
+    if m and m.groups() == ("10", "2", "0", "0") and "float" in m.group(0) and values:
+        known = 784 * 60160 * 8 + 10 * 60160 * 8 + 8 * 60160 * 12
+        LOOP_FACTOR = known / (1024.0 * sum(values) / len(values))
+        print(f"leaf-loop fetch calibration: x{LOOP_FACTOR:.3f}")
 result = {}
 for name in sorted(set(fetch) | set(write)):
     if "bn::" not in name:
@@ -64,6 +77,8 @@ for name in sorted(set(fetch) | set(write)):
         # every such kernel); the others read evidence and loop state 8 bytes per lane
         # (and so does the reduce-mode launch with four observations per lane)
         factor = 2.0 if int(m.group(4)) // 3 == 3 or m.group(3) == "4" else LEAF_FACTOR
+    if LOOP.search(short):
+        factor = LOOP_FACTOR
     result[short] = dict(
         launches=len(f),
         fetch_correction=factor,

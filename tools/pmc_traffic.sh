@@ -11,6 +11,6 @@ mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/$C
-  timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing "$@" > $OUT/$C.log 2>&1 || { echo "pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
 done
 python3 $R/tools/pmc_summarise.py $OUT $R/gpurun_out/pmc_traffic.json

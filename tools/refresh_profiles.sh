@@ -15,7 +15,7 @@ timeout -k 10 300 python3 bench.py --model c3b --no-cpu-baseline > $OUT/${TAG}_b
 timeout -k 10 300 python3 bench.py --model c5 --no-cpu-baseline > $OUT/${TAG}_bench_c5_131k.json 2> $OUT/bench_c5.err || { echo "bench c5 failed"; exit 1; }
 # 2. rocprofv3 kernel trace + stats of the same default command
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1 || { echo "rocprof stats failed"; tail -5 $OUT/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/stats.log 2>&1 || { echo "rocprof stats failed"; tail -5 $OUT/stats.log; exit 1; }
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_bench_c3a_60k.csv
 # 3. HBM traffic counters (two passes) and the MFMA utilisation pass on the deep tree
 cd $R
