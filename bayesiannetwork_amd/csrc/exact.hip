@@ -165,6 +165,10 @@ int bn_exact_create(int dtype, int32_t num_nodes, const int32_t* num_states, con
   if (parent_offsets[0] != 0 || parent_offsets[num_nodes] > bn::kExactMaxParentRefs)
     return fail(BN_ERR_INVALID, "parent offsets must start at 0 and hold at most " +
                                     std::to_string(bn::kExactMaxParentRefs) + " entries");
+  for (int32_t j = 0; j < num_nodes; ++j)
+    if (parent_offsets[j + 1] < parent_offsets[j]) return fail(BN_ERR_INVALID, "parent offsets must not decrease");
+  if (parent_offsets[num_nodes] > 0 && !parent_indices)
+    return fail(BN_ERR_INVALID, "parent_indices is NULL although some node has parents");
   bn_exact* x = new (std::nothrow) bn_exact();
   if (!x) return fail(BN_ERR_INVALID, "out of host memory");
   x->dtype = dtype;

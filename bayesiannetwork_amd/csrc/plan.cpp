@@ -57,6 +57,12 @@ std::string compile_plan(Plan& p, int dtype, int64_t num_observations, int32_t n
   if (num_nodes < 1) return "num_nodes must be >= 1";
   if (!num_states || !parent_offsets || !child_offsets) return "null topology array";
   if (num_observed < 0 || (num_observed > 0 && !observed_nodes)) return "bad observed_nodes";
+  if (parent_offsets[0] != 0 || child_offsets[0] != 0) return "CSR offsets must start at 0";
+  for (int32_t j = 0; j < num_nodes; ++j)  // before anything is indexed with them
+    if (parent_offsets[j + 1] < parent_offsets[j] || child_offsets[j + 1] < child_offsets[j])
+      return "CSR offsets must be non-decreasing";
+  if ((parent_offsets[num_nodes] > 0 && !parent_indices) || (child_offsets[num_nodes] > 0 && !child_indices))
+    return "null index array with a non-empty CSR";
 
   p.dtype = dtype;
   p.elem_size = dtype == 0 ? 4 : 8;

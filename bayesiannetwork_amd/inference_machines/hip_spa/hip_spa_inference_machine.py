@@ -111,6 +111,7 @@ class _PlanHandle:
         # the flat CPT tensor whose values the plan's snapshot is known to hold (weak reference and
         # the tensor's version counter at that time), set by ``em_step``
         self.snapshot_of = None
+        self.last_stream = None  # (raw handle, torch stream) of the plan's latest call
 
     def __del__(self):
         if self.handle:
@@ -243,7 +244,18 @@ class HipSpaInferenceMachine(IInferenceMachine):
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        return ctypes.c_void_p(_stream_handle(self._device))
+        """The current torch stream as the engine's ``void*``.  A plan's calls are ordered by the stream
+        they are issued on; when the stream changes between two calls on one plan (a pooled plan taken
+        over by a machine that works on another stream, a ``torch.cuda.stream`` block), the new stream
+        first waits for everything the old one was given."""
+        stream = torch.cuda.current_stream(self._device)
+        handle = stream.cuda_stream
+        last = self._owner.last_stream
+        if last is not None and last[0] != handle:
+            stream.wait_stream(last[1])
+        if last is None or last[0] != handle:
+            self._owner.last_stream = (handle, stream)
+        return ctypes.c_void_p(handle)
 
     def _restore_evidence(self) -> None:
         """After ``em_step`` the engine holds new parameters and no evidence; the batch's evidence is

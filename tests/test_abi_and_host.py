@@ -52,6 +52,15 @@ def test_plan_create_rejects_bad_topology_without_touching_the_gpu():
     assert create(0, 4, **mismatch) == -1 and b"disagree" in lib.bn_last_error()
     twice = dict(good, obs=[1, 1])
     assert create(0, 4, **twice) == -1 and b"twice" in lib.bn_last_error()
+    shifted = dict(good, p_off=[1, 1, 2], p_idx=[0, 0])
+    assert create(0, 4, **shifted) == -1 and b"start at 0" in lib.bn_last_error()
+    backwards = dict(good, p_off=[0, 1, 0])
+    assert create(0, 4, **backwards) == -1 and b"non-decreasing" in lib.bn_last_error()
+    # a non-empty CSR whose index array is missing
+    rc = lib.bn_plan_create(0, 4, 2, _native.i32_array(good["states"]), _native.i32_array(good["p_off"]), None,
+                            _native.i32_array(good["c_off"]), _native.i32_array(good["c_idx"]),
+                            _native.i32_array(good["obs"]), 1, ctypes.byref(handle))
+    assert rc == -1 and b"null index array" in lib.bn_last_error()
     assert lib.bn_plan_destroy(None) == 0
 
 
