@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dispatch_fast.h"
+#include "kernels_star.h"
 #include "error.h"
 #include "launch.h"
 #include "kernels_generic.h"
@@ -39,8 +40,24 @@ struct StepGraph {
   int32_t ll_blocks = 0;  // partial sums the sequence leaves for the final log-likelihood sum
 };
 
+// What the one-launch EM step of a star network needs (kernels_star.h); set up on first use.
+struct StarState {
+  bool checked = false, ok = false;
+  int32_t fgroup = -1, root = -1, d0 = 0, chunks = 0, chunk_len = 0, nslices = 0;
+  double* part_mant = nullptr;
+  int32_t* part_exp = nullptr;
+  double* count_part = nullptr;
+  double* root_part = nullptr;
+  double* ll_part = nullptr;
+  uint32_t* barrier = nullptr;  // arrival counters (kernels_star.h)
+  int32_t* error = nullptr;     // pinned host memory the kernel can write: a barrier wait ran out
+  uint32_t epoch = 0, slice_epoch = 0;
+};
+
 struct bn_plan {
   bn::Plan p;
+  StarState star;
+  bool star_wanted = true;  // bn_plan_enable_star_step
   std::map<std::string, StepGraph> graphs;  // by signature of the plan's state and the call's arguments
   hipStream_t capture_stream = nullptr;     // only ever captured on, never run
   double* accum_slot = nullptr;             // where a captured sequence leaves the count sums
@@ -661,6 +678,157 @@ bool step_graphs_enabled() {
 // batches up to this many tiles (of 256 float / 128 double observations) are launch-bound
 constexpr int64_t kStepGraphMaxTiles = 64;
 
+// BN_STAR_STEP=0 in the environment: never run an EM step as the one-launch star kernel
+bool star_steps_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("BN_STAR_STEP");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
+void release_star(bn_plan* plan) {
+  StarState& st = plan->star;
+  for (void* buffer : {(void*)st.part_mant, (void*)st.part_exp, (void*)st.count_part, (void*)st.root_part,
+                       (void*)st.ll_part, (void*)st.barrier})
+    if (buffer) (void)hipFree(buffer);
+  if (st.error) (void)hipHostFree(st.error);
+  st = StarState();
+}
+
+// Is the plan a star (kernels_star.h) small enough for the one-launch step?  Allocates its buffers.
+int prepare_star(bn_plan* plan) {
+  StarState& st = plan->star;
+  if (st.checked) return BN_OK;
+  st.checked = true;
+  bn::Plan& p = plan->p;
+  bn::FastState* fs = bn::fast_state(p);
+  if (!fs || fs->fused.size() != 1 || fs->wide.size() != 1) return BN_OK;
+  const auto& entry = *fs->fused.begin();
+  const bn::FusedFamily& fam = entry.second;
+  const bn::FactorGroup& g = p.fgroups[entry.first];
+  const bn::WideNode& w = fs->wide[fam.wide_index];
+  const int32_t K = (int32_t)g.nodes.size();
+  if (fam.wide_index2 >= 0 || g.dims.size() != 2 || g.dims[1] != 2 || K != p.n_nodes - 1) return BN_OK;
+  if (!p.parents[w.node].empty() || p.observed_slot_of[w.node] >= 0) return BN_OK;
+  if (w.uncovered.size() != 1 || w.uncovered[0] != w.I - 1) return BN_OK;
+  bool small = false;
+  switch (g.dims[0]) {
+#define X(DV) case DV: small = true; break;
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  if (!small) return BN_OK;
+  const int64_t nslices = p.npad / bn::kStarSlice;
+  if (p.npad % bn::kStarSlice != 0 || nslices < 1 || nslices > bn::kStarMaxSlices) return BN_OK;
+  // every block has to be resident at once: at most half of the device's CUs (a block fills one)
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) != hipSuccess) {
+    (void)hipGetLastError();
+    return BN_OK;
+  }
+  const int64_t max_blocks = std::min<int64_t>(bn::kStarMaxBlocks, cus / 2);
+  if (max_blocks < nslices) return BN_OK;
+  int32_t chunks = (int32_t)std::min<int64_t>(bn::kStarChunks, max_blocks / nslices);
+  chunks = std::max(1, std::min(chunks, K));
+  const int32_t chunk_len = (K + chunks - 1) / chunks;
+  chunks = (K + chunk_len - 1) / chunk_len;
+  if ((chunk_len + bn::kStarWaves - 1) / bn::kStarWaves > bn::kStarFamilies) return BN_OK;
+  st.fgroup = entry.first;
+  st.root = w.node;
+  st.d0 = g.dims[0];
+  st.chunks = chunks;
+  st.chunk_len = chunk_len;
+  st.nslices = (int32_t)nslices;
+  const size_t part = (size_t)2 * chunks * st.d0 * p.npad;
+  const size_t counts = (size_t)K * st.d0 * 2 * nslices;
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.part_mant), part * sizeof(double)));
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.part_exp), part * sizeof(int32_t)));
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.count_part), counts * sizeof(double)));
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.root_part), (size_t)nslices * st.d0 * sizeof(double)));
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.ll_part), (size_t)(chunks * nslices + nslices) * sizeof(double)));
+  const size_t counters = (size_t)(2 + bn::kStarMaxSlices) * bn::kStarCounterStride * sizeof(uint32_t);
+  BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.barrier), counters));
+  BN_HIP_CHECK(hipMemset(st.barrier, 0, counters));
+  BN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.error), sizeof(int32_t), hipHostMallocMapped));
+  *st.error = 0;
+  p.device_bytes += (int64_t)(part * 12 + counts * 8);
+  st.ok = true;
+  return BN_OK;
+}
+
+template <typename T, int D0>
+int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
+                double* ll_out_dev, void* new_cpts_dev, hipStream_t s) {
+  bn::Plan& p = plan->p;
+  StarState& st = plan->star;
+  bn::FastState* fs = bn::fast_state(p);
+  const bn::FactorGroup& g = p.fgroups[st.fgroup];
+  bn::StarArgs<T> a;
+  a.arena = static_cast<T*>(p.arena);
+  a.cpts = static_cast<T*>(p.cpts);
+  a.new_cpts = static_cast<T*>(new_cpts_dev);
+  a.obs_off = fs->fused.begin()->second.d_obs_off;
+  a.cpt_off = g.d_cpt;
+  a.root_cpt_off = p.cpt_off[st.root];
+  a.K = (int32_t)g.nodes.size();
+  a.C = st.chunks;
+  a.chunk_len = st.chunk_len;
+  a.nslices = st.nslices;
+  a.iterations = num_iterations;
+  a.N = p.N;
+  a.npad = p.npad;
+  a.part_mant = st.part_mant;
+  a.part_exp = st.part_exp;
+  a.count_part = st.count_part;
+  a.root_part = st.root_part;
+  a.ll_part = st.ll_part;
+  a.barrier = st.barrier;
+  a.epoch0 = st.epoch;
+  a.slice_epoch0 = st.slice_epoch;
+  a.error = st.error;
+  a.learning_rate = learning_rate;
+  a.regularization = regularization;
+  a.ll_scale = average ? 1.0 / (double)p.N : 1.0;
+  a.ll_out = ll_out_dev;
+  constexpr int32_t V = 2, NW = bn::kStarWaves;
+  const size_t lds = (size_t)(NW / 2) * D0 * V * 64 * 12 + (size_t)NW * V * 64 * 12 + (size_t)D0 * V * 64 * 12 +
+                     (size_t)NW * 64 * sizeof(double) + (size_t)D0 * V * 64 * 12 +
+                     (size_t)st.chunk_len * D0 * 2 * sizeof(T);
+  const void* kernel = reinterpret_cast<const void*>(&bn::star_em_step<T, D0>);
+  static bool lds_allowed = false;  // per instantiation
+  if (lds > 48 * 1024 && !lds_allowed) {
+    BN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_allowed = true;
+  }
+  void* args[] = {&a};
+  const uint32_t blocks = (uint32_t)(st.chunks * st.nslices);
+  static const bool cooperative = getenv("BN_STAR_COOPERATIVE") != nullptr;
+  const hipError_t err = cooperative ? hipLaunchCooperativeKernel(kernel, dim3(blocks), dim3(64 * NW), args,
+                                                                  (unsigned int)lds, s)
+                                     : hipLaunchKernel(kernel, dim3(blocks), dim3(64 * NW), args, lds, s);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;  // not launched: the caller takes the launch-per-pass route
+  }
+  st.epoch += blocks;                                                    // one grid-wide barrier per launch
+  st.slice_epoch += (uint32_t)(num_iterations - 1) * (uint32_t)st.chunks;  // one slice barrier per loop iteration
+  return BN_OK;
+}
+
+template <typename T>
+int launch_star_for_d0(bn_plan* plan, int32_t num_iterations, int32_t average, double learning_rate,
+                       double regularization, double* ll_out_dev, void* new_cpts_dev, hipStream_t s) {
+  switch (plan->star.d0) {
+#define X(DV) \
+  case DV:    \
+    return launch_star<T, DV>(plan, num_iterations, average, learning_rate, regularization, ll_out_dev, new_cpts_dev, s);
+    BN_SMALL_DIMS(X)
+#undef X
+  }
+  return 1;
+}
+
 void drop_step_graphs(bn_plan* plan) {
   for (auto& kv : plan->graphs) {
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -910,6 +1078,7 @@ int bn_plan_destroy(bn_plan* plan) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(plan->p.device);
   drop_step_graphs(plan);
+  release_star(plan);
   if (plan->capture_stream) (void)hipStreamDestroy(plan->capture_stream);
   if (plan->accum_slot) (void)hipFree(plan->accum_slot);
   bn::release_fast(plan->p);
@@ -942,6 +1111,12 @@ int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled) {
 }
 
 int64_t bn_plan_step_graph_launches(const bn_plan* plan) { return plan ? plan->graph_launches : -1; }
+
+int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  plan->star_wanted = enabled != 0;
+  return BN_OK;
+}
 
 int bn_set_cpts(bn_plan* plan, const void* cpts_dev, void* stream) {
   if (!plan || !cpts_dev) return fail(BN_ERR_INVALID, "null argument");
@@ -1360,6 +1535,35 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   hipStream_t s = static_cast<hipStream_t>(stream);
   // messages as a machine built for this batch would have them
   if (int rc = p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s)) return rc;
+  // Small batch of a star network: the whole step as one cooperative launch (kernels_star.h)
+  if (star_steps_enabled() && plan->star_wanted && num_iterations >= 2 && !g_profiling.load(std::memory_order_relaxed) && !plan->graphs_off) {
+    if (int rc = prepare_star(plan)) return rc;
+    if (plan->star.ok && *plan->star.error != 0) {
+      plan->star.ok = false;
+      return fail(BN_ERR_HIP, "an earlier one-launch EM step could not synchronise its blocks (the GPU was shared "
+                              "with other work); its results are void, this plan launches per pass from now on");
+    }
+    if (plan->star.ok) {
+      if (!p.observed.empty()) {
+        const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
+                                  : bn_enter_evidence(plan, evidence_dev, stream);
+        if (rc != BN_OK) return rc;
+      }
+      if (int rc = settle_observations(p, s)) return rc;
+      const int launched = p.dtype == BN_F32
+                               ? launch_star_for_d0<float>(plan, num_iterations, average, learning_rate, regularization,
+                                                           ll_out_dev, new_cpts_dev, s)
+                               : launch_star_for_d0<double>(plan, num_iterations, average, learning_rate, regularization,
+                                                            ll_out_dev, new_cpts_dev, s);
+      if (launched < 0) return launched;
+      if (launched == BN_OK) {
+        // new parameters, every stored message stale: as after bn_set_cpts + bn_reset_messages
+        bn::cpts_changed_fast(p);
+        return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
+      }
+      plan->star.ok = false;  // the runtime refused the cooperative launch: launch per pass from now on
+    }
+  }
   // evidence: read by the first iteration itself where bn_em_statistics_from[_states] would do so
   bool ingest = !p.observed.empty() && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0;
   if (ingest && states_dev) {

@@ -640,3 +640,9 @@ class HipSpaInferenceMachine(IInferenceMachine):
         """Small batches replay repeated ``em_statistics`` calls as a captured graph; ``False`` makes
         the engine launch kernel by kernel (same results)."""
         _native.check(self._lib.bn_plan_enable_step_graphs(self._plan, 1 if enabled else 0))
+
+    def enable_star_step(self, enabled: bool = True) -> None:
+        """``em_step`` on a small batch of a star network (one root, two-state leaves) is one
+        cooperative launch; ``False`` makes the engine take one launch per pass (results agree to
+        rounding)."""
+        _native.check(self._lib.bn_plan_enable_star_step(self._plan, 1 if enabled else 0))

@@ -113,6 +113,19 @@ int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled);
 int64_t bn_plan_step_graph_launches(const bn_plan* plan);
 
 /*
+ * bn_em_step on a small batch (at most 2048 observations) of a star network — one root whose
+ * children are all two-state leaves of one CPT shape, the latent-class model of
+ * dev_experiments/mnist/mnist.py — runs as ONE cooperative launch: the blocks keep their
+ * families' evidence in registers for all iterations and meet at a grid-wide barrier per iteration
+ * instead of ending a kernel per pass (the step is otherwise bound by its chain of sixteen
+ * dependent dispatches).  Same iterations, same formulas; sums are taken in another order, so
+ * results agree with the launch-per-pass route to rounding (1e-6 relative in float32), not bit for
+ * bit.  On by default; bn_plan_enable_star_step(plan, 0) switches a plan back to one launch per pass
+ * (BN_STAR_STEP=0 in the environment: the whole process).
+ */
+int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled);
+
+/*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
  * Replaces torch.stack(node.cpt ...) in FactorNodeGroup.__init__
  * (spa_v3/factor_graph.py:192).

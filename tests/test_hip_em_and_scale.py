@@ -579,6 +579,7 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
         for step in range(6):
             machine = HipSpaInferenceMachine(settings, network, observed, n)
             machine.enable_step_graphs(graphs and one_call)
+            machine.enable_star_step(False)  # one launch per pass: bit-identical to the separate calls
             if one_call:
                 ll, new = machine.em_step(batches[step % 2], 0.2, 0.01)
             else:
@@ -595,6 +596,7 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
                 trace.append(machine.log_likelihood_tensor().clone())
             model.assign(new)
             machine.enable_step_graphs(False)
+            machine.enable_star_step(True)
             del machine
         return trace
 
@@ -602,3 +604,46 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
     assert len(one) == len(separate)
     for a, b in zip(one, separate):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hard", [False, True])
+@pytest.mark.parametrize("n", [1, 64, 100, 129, 1000, 1024])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_one_launch_star_step_agrees_with_one_launch_per_pass(dtype, n, hard):
+    """The cooperative one-launch EM step of the 784-leaf model against the launch-per-pass route
+    (itself checked against the oracle above): log-likelihoods and parameters after each of four
+    steps, to rounding."""
+    import bench
+    from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    device = torch.device("cuda", 0)
+    settings = SpaInferenceMachineSettings(ts, True)
+
+    def run(star):
+        network, ys = bench.build_model(ts, "c3a")
+        batches = [bench.synthetic_evidence(ts, n, len(ys), 11 + b, device) for b in range(2)]
+        if hard:
+            batches = [HardEvidence(torch.stack([d.argmax(dim=1) for d in b.data]), [2] * len(ys), ts,
+                                    on_value=1.0 - 1e-6, off_value=1e-6) for b in batches]
+        model = FlatModel.of(network)
+        model.assign(model.gather())
+        trace = []
+        for step in range(4):
+            machine = HipSpaInferenceMachine(settings, network, ys, n)
+            machine.enable_star_step(star)
+            ll, new = machine.em_step(batches[step % 2], 0.3, 0.01)
+            trace.append((ll.clone(), new.clone()))
+            model.assign(new)
+            machine.enable_star_step(True)
+            del machine
+        return trace
+
+    tol = 2e-6 if dtype == "float32" else 1e-11
+    for (ll_a, new_a), (ll_b, new_b) in zip(run(True), run(False)):
+        assert torch.isfinite(ll_a).all()
+        assert abs(ll_a.item() - ll_b.item()) <= tol * abs(ll_b.item())
+        np.testing.assert_allclose(new_a.cpu().double().numpy(), new_b.cpu().double().numpy(), rtol=10 * tol, atol=tol)
