@@ -759,7 +759,7 @@ int prepare_star(bn_plan* plan) {
 
 template <typename T, int D0>
 int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
-                double* ll_out_dev, void* new_cpts_dev, hipStream_t s) {
+                double* ll_out_dev, void* new_cpts_dev, hipStream_t s, bool from_caller) {
   bn::Plan& p = plan->p;
   StarState& st = plan->star;
   bn::FastState* fs = bn::fast_state(p);
@@ -769,6 +769,7 @@ int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double l
   a.cpts = static_cast<T*>(p.cpts);
   a.new_cpts = static_cast<T*>(new_cpts_dev);
   a.obs_off = fs->fused.begin()->second.d_obs_off;
+  a.src = from_caller ? fs->fused.begin()->second.d_src : nullptr;
   a.cpt_off = g.d_cpt;
   a.root_cpt_off = p.cpt_off[st.root];
   a.K = (int32_t)g.nodes.size();
@@ -818,11 +819,12 @@ int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double l
 
 template <typename T>
 int launch_star_for_d0(bn_plan* plan, int32_t num_iterations, int32_t average, double learning_rate,
-                       double regularization, double* ll_out_dev, void* new_cpts_dev, hipStream_t s) {
+                       double regularization, double* ll_out_dev, void* new_cpts_dev, hipStream_t s, bool from_caller) {
   switch (plan->star.d0) {
 #define X(DV) \
   case DV:    \
-    return launch_star<T, DV>(plan, num_iterations, average, learning_rate, regularization, ll_out_dev, new_cpts_dev, s);
+    return launch_star<T, DV>(plan, num_iterations, average, learning_rate, regularization, ll_out_dev, new_cpts_dev, s, \
+                              from_caller);
     BN_SMALL_DIMS(X)
 #undef X
   }
@@ -1544,17 +1546,26 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
                               "with other work); its results are void, this plan launches per pass from now on");
     }
     if (plan->star.ok) {
-      if (!p.observed.empty()) {
-        const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
-                                  : bn_enter_evidence(plan, evidence_dev, stream);
-        if (rc != BN_OK) return rc;
+      // float evidence in 16-byte aligned arrays is read where it lies (the plan's copy would be
+      // void after the step anyway); anything else goes into the observation arrays first
+      bool from_caller = !p.observed.empty() && evidence_dev && !states_dev;
+      for (size_t i = 0; i < p.observed.size() && from_caller; ++i)
+        from_caller = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
+      if (from_caller) {
+        if (int rc = upload_family_sources(p, evidence_dev, s)) return rc;
+      } else {
+        if (!p.observed.empty()) {
+          const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
+                                    : bn_enter_evidence(plan, evidence_dev, stream);
+          if (rc != BN_OK) return rc;
+        }
+        if (int rc = settle_observations(p, s)) return rc;
       }
-      if (int rc = settle_observations(p, s)) return rc;
       const int launched = p.dtype == BN_F32
                                ? launch_star_for_d0<float>(plan, num_iterations, average, learning_rate, regularization,
-                                                           ll_out_dev, new_cpts_dev, s)
+                                                           ll_out_dev, new_cpts_dev, s, from_caller)
                                : launch_star_for_d0<double>(plan, num_iterations, average, learning_rate, regularization,
-                                                            ll_out_dev, new_cpts_dev, s);
+                                                            ll_out_dev, new_cpts_dev, s, from_caller);
       if (launched < 0) return launched;
       if (launched == BN_OK) {
         // new parameters, every stored message stale: as after bn_set_cpts + bn_reset_messages

@@ -45,6 +45,10 @@ struct StarArgs {
   T* cpts;       // the plan's CPT snapshot: read during the step, overwritten by the M-step
   T* new_cpts;   // the caller's copy of the new CPTs
   const int64_t* obs_off;  // [K] observation array (or the all-ones array) of each leaf
+  // non-null: the evidence is read from the caller's [N][2] arrays instead (one pointer per leaf;
+  // for a leaf that is not observed, its all-ones array in the arena, which has the same shape up
+  // to N).  The plan's own copy is not needed: the step ends with the plan reset.
+  const void* const* src;
   const int64_t* cpt_off;  // [K] element offset of each leaf's CPT
   int64_t root_cpt_off;
   int32_t K, C, chunk_len, nslices, iterations;
@@ -141,7 +145,27 @@ __global__ void __launch_bounds__(64 * kStarWaves) star_em_step(StarArgs<T> a) {
   for (int32_t f = 0; f < F; ++f)
 #pragma unroll
     for (int32_t j = 0; j < S; ++j)
-      ev[f][j] = f < nf ? loadv<T, V>(a.arena + a.obs_off[lo + f], t * S + j, col) : splat<T, V>((T)1);
+      ev[f][j] = f < nf && !a.src ? loadv<T, V>(a.arena + a.obs_off[lo + f], t * S + j, col) : splat<T, V>((T)1);
+  if (a.src) {
+    // [observation][state]: the lane's two observations x two states are 4 consecutive elements
+    // (padding observations, and the second one of an odd batch's last lane, count as all ones)
+#pragma unroll
+    for (int32_t f = 0; f < F; ++f) {
+      if (f < nf && obs0 < a.N) {
+        const T* rows = static_cast<const T*>(a.src[lo + f]) + obs0 * S;
+        if (obs0 + 1 < a.N) {
+          const fv<T, 4> raw = *reinterpret_cast<const fv<T, 4>*>(rows);
+          ev[f][0][0] = raw[0];
+          ev[f][1][0] = raw[1];
+          ev[f][0][1] = raw[2];
+          ev[f][1][1] = raw[3];
+        } else {
+          ev[f][0][0] = rows[0];
+          ev[f][1][0] = rows[1];
+        }
+      }
+    }
+  }
   const T* prior = a.cpts + a.root_cpt_off;
   // the CPT rows of the block's families, fetched by all threads at once (two memory round trips
   // for the lot instead of two per family) and read from LDS from then on

@@ -52,6 +52,9 @@ class EmBatchOptimizer(IBatchOptimizer):
                         machine = self._factory(self._network)
                     ll, flat = machine.em_step(evidence, cfg.learning_rate, cfg.regularization)
                     flat_model.assign(flat)
+                    # back to the pool before the next machine is built: that one then gets this very
+                    # plan, which already holds the new parameters
+                    machine = None
                     if not deferred:
                         ll = ll.item()
                     if deferred:

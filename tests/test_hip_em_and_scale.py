@@ -638,6 +638,11 @@ def test_one_launch_star_step_agrees_with_one_launch_per_pass(dtype, n, hard):
             ll, new = machine.em_step(batches[step % 2], 0.3, 0.01)
             trace.append((ll.clone(), new.clone()))
             model.assign(new)
+            if step == 2:
+                # asked after its step, the machine answers for the batch's evidence under the new parameters
+                # (the one-launch step leaves no evidence in the plan: the machine enters it again)
+                trace.append((machine.log_likelihood_tensor().clone(),
+                              machine.infer_single_nodes([list(network.nodes)[0]])[0].reshape(-1).clone()))
             machine.enable_star_step(True)
             del machine
         return trace
