@@ -113,7 +113,7 @@ int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled);
 int64_t bn_plan_step_graph_launches(const bn_plan* plan);
 
 /*
- * bn_em_step on a small batch (at most 2048 observations) of a star network — one root whose
+ * bn_em_step on a small batch (at most 1024 observations) of a star network — one root whose
  * children are all two-state leaves of one CPT shape, the latent-class model of
  * dev_experiments/mnist/mnist.py — runs as ONE cooperative launch: the blocks keep their
  * families' evidence in registers for all iterations and meet at a grid-wide barrier per iteration
