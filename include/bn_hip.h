@@ -115,12 +115,15 @@ int64_t bn_plan_step_graph_launches(const bn_plan* plan);
 /*
  * bn_em_step on a small batch (at most 1024 observations) of a star network — one root whose
  * children are all two-state leaves of one CPT shape, the latent-class model of
- * dev_experiments/mnist/mnist.py — runs as ONE cooperative launch: the blocks keep their
- * families' evidence in registers for all iterations and meet at a grid-wide barrier per iteration
+ * dev_experiments/mnist/mnist.py — runs as ONE persistent launch of at most 128 blocks: the blocks
+ * keep their families' evidence in registers for all iterations and meet at a barrier per iteration
  * instead of ending a kernel per pass (the step is otherwise bound by its chain of sixteen
  * dependent dispatches).  Same iterations, same formulas; sums are taken in another order, so
- * results agree with the launch-per-pass route to rounding (1e-6 relative in float32), not bit for
- * bit.  On by default; bn_plan_enable_star_step(plan, 0) switches a plan back to one launch per pass
+ * results agree with the launch-per-pass route to rounding (2e-6 relative in float32), not bit for
+ * bit.  The barriers need all blocks on the GPU at once; their wait is bounded, and a step whose
+ * blocks could not meet (a GPU shared with other work) yields a NaN log-likelihood, after which
+ * the next bn_em_step on the plan returns BN_ERR_HIP and the plan launches per pass from then on.
+ * On by default; bn_plan_enable_star_step(plan, 0) switches a plan back to one launch per pass
  * (BN_STAR_STEP=0 in the environment: the whole process).
  */
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled);
