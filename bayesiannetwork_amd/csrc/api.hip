@@ -452,7 +452,27 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
   // last one runs in full mode; a statistics call on fresh messages touches neither
   if (iterations > 0 && (!p.fresh || reduce_last == 0))
     if (int rc = ensure_message_arrays(p)) return rc;
+  // A tree of dense one-parent families: the first and the last iteration(s) run as separate variable
+  // and factor passes (the first consumes the fresh / evidence state, the last writes the variable ->
+  // factor messages and the normalisers that queries read); an even number of iterations in between
+  // runs as one launch per factor group, each reading one generation of factor -> variable messages
+  // and writing the other, so that the newest generation ends up in the usual arrays.
+  const int32_t tree_count = bn::tree_iterations_possible(p) && iterations >= 4 ? ((iterations - 2) & ~1) : 0;
   for (int32_t it = 0; it < iterations; ++it) {
+    if (it >= 1 && it <= tree_count) {
+      for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
+        const bn::FactorGroup& g = p.fgroups[fi];
+        if (g.dims.size() != 2) continue;
+        const bn::TreeGroupTables& tables = bn::fast_state(p)->tree.at((int32_t)fi);
+        const bool exact = it == tree_count;
+        prof_begin(flabel(exact ? "tree_iteration_exact" : "tree_iteration", g),
+                   (tables.bytes_per_observation + (exact ? tables.exact_bytes_per_observation : 0.0)) * (double)p.npad, s);
+        if (!bn::launch_tree_iteration(p, fi, (it - 1) & 1, exact, s))
+          return fail(BN_ERR_HIP, "launch of factor_tree_mfma failed");
+        prof_end(s);
+      }
+      continue;
+    }
     const int32_t fresh = p.fresh ? 1 : 0;
     for (auto& g : p.vgroups) {
       const int32_t K = (int32_t)g.nodes.size();

@@ -69,6 +69,13 @@ inline void release_fast(Plan& p) {
     if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
     if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
+  for (auto& kv : st->tree)
+    for (int32_t gen = 0; gen < 2; ++gen) {
+      if (kv.second.in_par[gen]) (void)hipFree(kv.second.in_par[gen]);
+      if (kv.second.in_own[gen]) (void)hipFree(kv.second.in_own[gen]);
+      if (kv.second.own_prev[gen]) (void)hipFree(kv.second.own_prev[gen]);
+      if (kv.second.out[gen]) (void)hipFree(kv.second.out[gen]);
+    }
   if (st->d_ll_offs) (void)hipFree(st->d_ll_offs);
   if (st->d_unfused_entries) (void)hipFree(st->d_unfused_entries);
   delete st;
@@ -108,6 +115,105 @@ inline bool ingest_states_possible(const Plan& p) {
 
 inline void cpts_changed_fast(Plan& p) {
   if (FastState* st = fast_state(p)) std::fill(st->root_written.begin(), st->root_written.end(), 0);
+}
+
+// Tables for the fused tree iteration, if the plan qualifies (FastState::tree_ok).
+inline int prepare_tree(Plan& p, FastState& st) {
+  st.tree_ok = false;
+  if (p.dtype != 0 || !st.wide.empty() || !st.fused.empty()) return 0;
+  auto dense = [](int32_t d) { return d == 32 || d == 64; };
+  bool any = false;
+  for (const FactorGroup& g : p.fgroups) {
+    if (g.dims.size() == 1) continue;
+    if (g.dims.size() != 2 || !dense(g.dims[0]) || !dense(g.dims[1])) return 0;
+    any = true;
+  }
+  if (!any) return 0;
+  auto generation = [&](const EdgeLayout& e, int32_t gen) {
+    // the message of a parentless factor (the prior) never changes: one array for both generations
+    if (e.owner == e.var && p.parents[e.owner].empty()) return e.f2v;
+    return gen == 0 ? e.f2v : e.v2f;
+  };
+  // messages a variable receives, except the one from factor `except_owner`
+  auto others = [&](int32_t var, int32_t except_owner, int32_t gen, std::vector<int64_t>& out) {
+    if (except_owner != var) out.push_back(generation(p.edges[var], gen));
+    for (int32_t child : p.children[var]) {
+      if (child == except_owner) continue;
+      const auto& cp = p.parents[child];
+      const int32_t pos = (int32_t)(std::find(cp.begin(), cp.end(), var) - cp.begin());
+      out.push_back(generation(p.edges[p.parent_edge_base[child] + pos], gen));
+    }
+    if (p.observed_slot_of[var] >= 0) out.push_back(p.obs_off[p.observed_slot_of[var]]);
+  };
+  std::map<int32_t, std::vector<int64_t>> host[2][4];  // [generation][in_par, in_own, own_prev, out]
+  for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
+    const FactorGroup& g = p.fgroups[fi];
+    if (g.dims.size() != 2) continue;
+    double arrays = 0;
+    for (int32_t gen = 0; gen < 2; ++gen) {
+      for (int32_t j : g.nodes) {
+        const int32_t parent = p.parents[j][0];
+        std::vector<int64_t> par, own;
+        others(parent, j, gen, par);
+        others(j, j, gen, own);
+        if (par.empty() || par.size() > 2 || own.size() > 2) return 0;
+        if (gen == 0) arrays += (double)par.size() * g.dims[0] + (double)own.size() * g.dims[1] + g.dims[0] + g.dims[1];
+        par.resize(2, kNoArray);
+        own.resize(2, kNoArray);
+        const EdgeLayout& e_own = p.edges[j];
+        const EdgeLayout& e_par = p.edges[p.parent_edge_base[j]];
+        auto& h = host[gen];
+        h[0][(int32_t)fi].insert(h[0][(int32_t)fi].end(), par.begin(), par.end());
+        h[1][(int32_t)fi].insert(h[1][(int32_t)fi].end(), own.begin(), own.end());
+        h[2][(int32_t)fi].push_back(generation(e_own, gen));
+        h[3][(int32_t)fi].push_back(generation(e_par, 1 - gen));
+        h[3][(int32_t)fi].push_back(generation(e_own, 1 - gen));
+      }
+    }
+    st.tree[(int32_t)fi].bytes_per_observation = arrays * (double)p.elem_size;
+    st.tree[(int32_t)fi].exact_bytes_per_observation = (double)g.nodes.size() * g.dims[1] * (double)p.elem_size;
+  }
+  for (auto& kv : st.tree) {
+    for (int32_t gen = 0; gen < 2; ++gen) {
+      if (!dev_upload(host[gen][0][kv.first], &kv.second.in_par[gen], p.device_bytes) ||
+          !dev_upload(host[gen][1][kv.first], &kv.second.in_own[gen], p.device_bytes) ||
+          !dev_upload(host[gen][2][kv.first], &kv.second.own_prev[gen], p.device_bytes) ||
+          !dev_upload(host[gen][3][kv.first], &kv.second.out[gen], p.device_bytes))
+        return -2;
+    }
+  }
+  st.tree_ok = true;
+  return 0;
+}
+
+// One fused flooding iteration of generation `gen` (0: f2v arrays -> v2f arrays, 1: back) for the
+// dense factor group fi.  Returns false on a launch failure.
+inline bool launch_tree_iteration(Plan& p, size_t fi, int32_t gen, bool exact, hipStream_t s) {
+  FastState* st = fast_state(p);
+  const FactorGroup& g = p.fgroups[fi];
+  const TreeGroupTables& t = st->tree.at((int32_t)fi);
+  TreeFamilyTables tab{t.in_par[gen], t.in_own[gen], t.own_prev[gen], t.out[gen], g.d_cpt};
+  const int32_t K = (int32_t)g.nodes.size();
+  const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
+  float* arena = static_cast<float*>(p.arena);
+  const float* cpts = static_cast<const float*>(p.cpts);
+  using Fn = void (*)(float*, const float*, TreeFamilyTables, int32_t, int64_t);
+  const int32_t d0 = g.dims[0], sv = g.dims[1];
+  Fn fn = d0 == 64 ? (sv == 64 ? (exact ? factor_tree_mfma<64, 64, true> : factor_tree_mfma<64, 64, false>)
+                               : (exact ? factor_tree_mfma<64, 32, true> : factor_tree_mfma<64, 32, false>))
+                   : (sv == 64 ? (exact ? factor_tree_mfma<32, 64, true> : factor_tree_mfma<32, 64, false>)
+                               : (exact ? factor_tree_mfma<32, 32, true> : factor_tree_mfma<32, 32, false>));
+  launch(fn, grid, dim3(256), 0, s, arena, cpts, tab, K, p.ntiles);
+  return launch_ok();
+}
+
+inline bool tree_iterations_possible(const Plan& p) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("BN_TREE_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  FastState* st = fast_state(p);
+  return enabled && st && st->tree_ok;
 }
 
 inline int prepare_fast(Plan& p) {
@@ -375,6 +481,7 @@ inline int prepare_fast(Plan& p) {
       }
     }
   }
+  if (int rc = prepare_tree(p, st)) return rc;
   // which launches touch the lazy region (see variable_needs_arrays / factor_needs_arrays)
   st.vgroup_lazy.assign(p.vgroups.size(), 0);
   st.fgroup_lazy.assign(p.fgroups.size(), 0);

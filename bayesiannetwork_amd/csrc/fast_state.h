@@ -71,7 +71,23 @@ struct FusedFamily {
 
 constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2;
 
+// Device tables of one dense factor group for the fused tree iteration (kernels_dense.h,
+// factor_tree_mfma), one set per generation: generation g reads the factor -> variable messages
+// from the f2v arrays (g = 0) or from the v2f arrays (g = 1) of the edges and writes the other.
+struct TreeGroupTables {
+  int64_t* in_par[2] = {nullptr, nullptr};
+  int64_t* in_own[2] = {nullptr, nullptr};
+  int64_t* own_prev[2] = {nullptr, nullptr};
+  int64_t* out[2] = {nullptr, nullptr};
+  double bytes_per_observation = 0;        // what one launch moves per observation (profiling)
+  double exact_bytes_per_observation = 0;  // more for the launch that reads the own_prev arrays
+};
+
 struct FastState {
+  // fused tree iterations: every non-root family is a dense 32 / 64-state one-parent family whose
+  // two variables each receive at most two other messages
+  bool tree_ok = false;
+  std::map<int32_t, TreeGroupTables> tree;  // by factor group
   // normaliser arrays of the nodes no fused family serves (the rest of a log-likelihood sum
   // comes from the families' ll_part rows when their last iteration ran in reduce mode)
   int64_t* d_ll_offs = nullptr;

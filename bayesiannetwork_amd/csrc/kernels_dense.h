@@ -122,6 +122,172 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) f
 }
 
 // ---------------------------------------------------------------------------------
+// One whole flooding iteration for a dense family (parent P with D0 states -> X with S states) in
+// one kernel: the variable passes of P and X, as far as this family's factor needs them, folded
+// into the factor pass.  The factor's two inputs are not read as stored messages but formed from
+// what P and X receive from elsewhere:
+//   u_P[a] = prod of P's inputs other than this factor's message  (its own factor's message, the
+//            other child's factor message, its observation): 1 or 2 arrays,
+//   u_X[b] = prod of X's inputs other than this factor's message  (its children's factor messages
+//            or its observation): 0, 1 or 2 arrays,
+// normalised as the variable pass does (VariableNodeGroup.calculate_outputs, spa_v3/factor_graph.py:
+// 112-144): P's message to a child's factor by its own sum over the states, X's message to its own
+// factor by the sum of X's FULL product, i.e. sum_b u_X[b] * (this factor's previous message to
+// X)[b] — that message is read for the normaliser only.  Then contracted with the CPT as in
+// factor_p1_mfma (FactorNodeGroup.calculate_outputs, :251-298).  Normalisation commutes with the contraction, so the unnormalised products are the
+// MFMA operands — they stay in registers, 64 per lane and side — and the accumulators are scaled
+// by 1 / sum afterwards.  With two inputs each is first scaled by a power of two so that its
+// largest entry per observation is in [0.5, 1): a product of two float messages that are tiny
+// throughout does not underflow.
+// Only factor -> variable messages exist between such iterations (a variable -> factor message
+// costs a write and a read of 64 floats per observation and edge: 2.3 KB per family, observation and
+// iteration in two passes, 1.3 KB here); they alternate between the two arrays of every edge, so
+// no launch reads what it writes.   Same geometry as factor_p1_mfma.
+struct TreeFamilyTables {
+  const int64_t* in_par;  // [K][2] arrays whose product is u_P (kNoArray = none)
+  const int64_t* in_own;  // [K][2] arrays whose product is u_X
+  const int64_t* own_prev;  // [K] the factor's previous message to X (weights of X's normaliser)
+  const int64_t* out;     // [K][2] where the messages to P and to X go
+  const int64_t* cpt_off;
+};
+
+// u[ks] = product of the (one or two) arrays for state 2 * ks + half and observation column `col` of
+// the 32-column block at `base` (already offset to tile, wave and column block); inv = 1 / sum
+// over the states of u (times the weight array's entry, when there is one).
+template <int KD>
+__device__ __forceinline__ void tree_operand(const float* __restrict__ arena, int64_t first, int64_t second,
+                                             int64_t weight, int64_t base, int32_t half, int32_t col,
+                                             float (&u)[KD / 2], float& inv) {
+  // 2^-exponent of the largest entry of the observation's column over all KD states (this lane holds
+  // every other state, the lane 32 further on the rest)
+  auto column_scale = [&](float mx) {
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    int e = 0;
+    (void)frexpf(mx, &e);
+    return ldexpf(1.0f, mx > 0.f ? -e : 0);
+  };
+  if (first == kNoArray) {
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 2; ++ks) u[ks] = 1.0f;
+  } else {
+    const float* a0 = arena + first + base + half * kTile + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 2; ++ks) u[ks] = a0[(int64_t)(2 * ks) * kTile];
+    if (second != kNoArray) {
+      const float* a1 = arena + second + base + half * kTile + col;
+      float v[KD / 2];
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 2; ++ks) v[ks] = a1[(int64_t)(2 * ks) * kTile];
+      float mu = 0.f, mv = 0.f;
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 2; ++ks) {
+        mu = fmaxf(mu, u[ks]);
+        mv = fmaxf(mv, v[ks]);
+      }
+      // each input scaled so that its largest entry is in [0.5, 1) before the two are multiplied
+      const float su = column_scale(mu), sv = column_scale(mv);
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 2; ++ks) u[ks] = (u[ks] * su) * (v[ks] * sv);
+    }
+  }
+  double sum = 0.0;
+  if (weight != kNoArray) {
+    __builtin_amdgcn_sched_barrier(0);  // the weights' loads after the inputs' registers are free
+    const float* wgt = arena + weight + base + half * kTile + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 2; ++ks) sum += (double)u[ks] * (double)wgt[(int64_t)(2 * ks) * kTile];
+  } else {
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 2; ++ks) sum += (double)u[ks];
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  inv = (float)(1.0 / sum);
+}
+
+// EXACT: X's message to its own factor is normalised as the reference does (weights = the factor's
+// previous message to X).  Without it that message is normalised by its own sum, which changes the
+// scale of this launch's message to the parent and nothing else; the scale of a message does not
+// survive the next normalisation, so only the last launch before a regular iteration (whose
+// normalisers the log-likelihood reads) has to be EXACT, and the others save reading one array.
+template <int D0, int S, bool EXACT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) factor_tree_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
+                                                       TreeFamilyTables tab, int32_t K, int64_t ntiles) {
+  __shared__ float w_lds[D0 * kCptPitch];
+  const int64_t item = blockIdx.x;
+  const int32_t k = (int32_t)(item / ntiles);
+  const int64_t t = item % ntiles;
+  if (k >= K) return;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t half = lane >> 5, col = lane & 31;
+
+  const float* cpt = cpts + tab.cpt_off[k];
+  for (int32_t e = threadIdx.x; e < D0 * S; e += 256) w_lds[(e / S) * kCptPitch + (e % S)] = cpt[e];
+  __syncthreads();
+  const int64_t in_par0 = tab.in_par[2 * k], in_par1 = tab.in_par[2 * k + 1];
+  const int64_t in_own0 = tab.in_own[2 * k], in_own1 = tab.in_own[2 * k + 1];
+  const int64_t own_prev = EXACT ? tab.own_prev[k] : kNoArray;
+  const int64_t out_par_off = tab.out[2 * k], out_own_off = tab.out[2 * k + 1];
+
+  // the wave's 64 observations as two blocks of 32 columns, one after the other (one block's
+  // operands and accumulators in registers at a time)
+#pragma unroll 1
+  for (int32_t jt = 0; jt < 2; ++jt) {
+    const int32_t column = wave * 64 + 32 * jt;
+    // ---- to own variable: out_own^T[b][n] = sum_a cpt[a][b] * u_P[a][n] / sum_a u_P[a][n]
+    {
+      float u[D0 / 2], inv;
+      tree_operand<D0>(arena, in_par0, in_par1, kNoArray, t * D0 * kTile + column, half, col, u, inv);
+      __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: the scheduler otherwise pulls the next
+                                          // phase's loads up and runs out of registers
+      f32x16 acc[S / 32];
+#pragma unroll
+      for (int32_t it = 0; it < S / 32; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r) acc[it][r] = 0.f;
+#pragma unroll
+      for (int32_t ks = 0; ks < D0 / 2; ++ks) {
+        const int32_t a = 2 * ks + half;
+#pragma unroll
+        for (int32_t it = 0; it < S / 32; ++it)  // W[i=b][k=a] = cpt[a][b]
+          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_lds[a * kCptPitch + 32 * it + col], u[ks], acc[it], 0, 0, 0);
+      }
+      float* out_own = arena + out_own_off + t * S * kTile + column + col;
+#pragma unroll
+      for (int32_t it = 0; it < S / 32; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r)
+          out_own[(int64_t)(32 * it + mfma_row(r, lane)) * kTile] = acc[it][r] * inv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- to parent: out_par^T[a][n] = sum_b cpt[a][b] * u_X[b][n] / (normaliser of X's message)
+    {
+      float u[S / 2], inv;
+      tree_operand<S>(arena, in_own0, in_own1, own_prev, t * S * kTile + column, half, col, u, inv);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 acc[D0 / 32];
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 32; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r) acc[it][r] = 0.f;
+#pragma unroll
+      for (int32_t ks = 0; ks < S / 2; ++ks) {
+        const int32_t b = 2 * ks + half;
+#pragma unroll
+        for (int32_t it = 0; it < D0 / 32; ++it)  // W[i=a][k=b] = cpt[a][b]
+          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_lds[(32 * it + col) * kCptPitch + b], u[ks], acc[it], 0, 0, 0);
+      }
+      float* out_par = arena + out_par_off + t * D0 * kTile + column + col;
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 32; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r)
+          out_par[(int64_t)(32 * it + mfma_row(r, lane)) * kTile] = acc[it][r] * inv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // EM count matrix for the same families: stat[a][b] = sum_n in_par[n][a] * in_own[n][b]
 // (the CPT factor is applied by em_finalize) = a [D0 x N] x [N x S] GEMM with the
 // observations as the k dimension.  One workgroup per (node, chunk of tiles); 64 observations

@@ -302,3 +302,114 @@ def test_deep_tree_of_64_state_nodes_at_benchmark_depth(dtype):
         want = oracle.infer_family(j).sum(dim=0)
         _check(counts[j], want, f"counts {name}", f32)
         _check(counts2[j], want, f"counts via statistics {name}", f32)
+
+
+def _mixed_tree(device, dtype="float32"):
+    """A tree of 32- and 64-state one-parent families whose variables receive at most two other
+    messages: every (parent states, own states) combination of the dense factor kernels, a chain
+    node with a single child, an observed inner node and observed leaves."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device=device, dtype=dtype)
+    gen = torch.Generator().manual_seed(17)
+    made = {}
+    builder = BayesianNetworkBuilder()
+
+    def add(name, states, parent=None):
+        shape = (states,) if parent is None else (made[parent].num_states, states)
+        made[name] = Node(_rand_cpt(gen, shape).to(ts.dtype).to(ts.device), name=name)
+        builder.add_node(made[name], parents=None if parent is None else made[parent])
+
+    add("R", 64)
+    add("A", 32, "R"); add("B", 64, "R")          # 64x32, 64x64
+    add("C", 32, "A"); add("D", 64, "A")          # 32x32, 32x64
+    add("E", 64, "B")                             # B: one child only
+    add("F", 32, "E"); add("G", 64, "E")
+    add("O", 64, "C")                             # observed inner node with a child of its own
+    add("Y0", 32, "O"); add("Y1", 64, "C"); add("Y2", 32, "D"); add("Y3", 64, "D")
+    add("Y4", 64, "F"); add("Y5", 32, "G"); add("Y6", 32, "G")
+    observed = [made[k] for k in ("O", "Y0", "Y1", "Y2", "Y3", "Y4", "Y5", "Y6")]
+    return ts, builder.build(), observed
+
+
+@pytest.mark.parametrize("iterations", [4, 5, 6, 9, None])
+def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations):
+    """Trees of dense one-parent families run their middle iterations as one launch per factor group
+    that reads and writes factor -> variable messages only.  Iteration counts below the diameter
+    leave the messages unconverged, so every message, normaliser and marginal depends on each
+    iteration having been carried out exactly as a variable pass followed by a factor pass;
+    compared with the float64 oracle after the same number of iterations (1e-5 relative), and with
+    the same machine driven one iteration per call (the per-call route never fuses)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from oracle.spa_oracle import SpaOracle
+
+    n = 333
+    ts, network, observed = _mixed_tree("cuda")
+    gen = torch.Generator().manual_seed(23)
+    evidence = []
+    for node in observed:
+        s = node.num_states
+        idx = torch.randint(0, s, (n,), generator=gen)
+        hard = torch.nn.functional.one_hot(idx, s).double() * (1 - 1e-6) + 1e-6 / s
+        soft = torch.rand((n, s), generator=gen, dtype=torch.float64) + 1e-3
+        pick = (torch.rand((n, 1), generator=gen) < 0.5).double()
+        evidence.append((pick * hard + (1 - pick) * soft / soft.sum(-1, keepdim=True)).to(ts.dtype))
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations)
+    machine = HipSpaInferenceMachine(settings, network, observed, n)
+    machine.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
+    # the route under test is the one taken: all but the first and the last one or two iterations
+    from bayesiannetwork_amd.inference_machines.hip_spa.hip_spa_inference_machine import enable_profiling, profile_report
+
+    enable_profiling(True)
+    try:
+        profile_report()
+        machine.log_likelihood()
+        report = profile_report()
+    finally:
+        enable_profiling(False)
+    fused = sum(r["launches"] for r in report if r["kernel"].startswith("tree_iteration"))
+    groups = len({r["kernel"] for r in report if r["kernel"].startswith("factor_pass[") and "x" in r["kernel"]})
+    assert groups == 4 and fused == groups * ((machine.num_iterations - 2) & ~1), report
+
+    _, network64, observed64 = _mixed_tree("cpu", "float64")
+    for node64, node in zip(network64.nodes, network.nodes):
+        node64.cpt = node.cpt.detach().cpu().double()
+    oracle = SpaOracle(network64, observed64, n, dtype=torch.float64, num_iterations=iterations)
+    oracle.enter_evidence([e.double() for e in evidence])
+    assert machine.num_iterations == oracle.num_iterations
+
+    nodes = list(network.nodes)
+    index = {node: j for j, node in enumerate(nodes)}
+    want_ll = oracle.log_likelihood(False)
+    assert abs(machine.log_likelihood() - want_ll) <= 1e-5 * abs(want_ll)
+    for node in nodes:
+        j = index[node]
+        _check(machine.infer_single_nodes([node])[0], oracle.infer_single(j), f"single {node.name}", True)
+        _check(machine.infer_nodes_with_parents([node])[0], oracle.infer_family(j), f"family {node.name}", True)
+        for owner in [node] + list(network.children_of(node)):
+            for kind, fn in (("f2v", oracle.message_f2v), ("v2f", oracle.message_v2f)):
+                _check(machine.message(node, owner, kind), fn(j, index[owner]),
+                       f"{kind} {node.name} / factor of {owner.name}", True)
+
+    # one iteration per call: the callback route
+    seen = []
+    stepwise = HipSpaInferenceMachine(
+        SpaInferenceMachineSettings(ts, False, num_iterations=iterations, callback=lambda *a: seen.append(1)),
+        network, observed, n)
+    stepwise.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
+    assert abs(stepwise.log_likelihood() - machine.log_likelihood()) <= 2e-6 * abs(want_ll)
+    assert len(seen) == machine.num_iterations
+    for node in nodes:
+        for owner in [node] + list(network.children_of(node)):
+            a = machine.message(node, owner, "f2v").double()
+            b = stepwise.message(node, owner, "f2v").double()
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-30), (node.name, owner.name)
+
+    # the one-call statistics route (last iteration in reduce mode) on a second machine
+    second = HipSpaInferenceMachine(settings, network, observed, n)
+    ll2, flat2 = second.em_statistics(Evidence([e.cuda() for e in evidence], ts))
+    assert abs(ll2.item() - want_ll) <= 1e-5 * abs(want_ll)
+    for j, got in enumerate(second.split_counts(flat2)):
+        _check(got, oracle.infer_family(j).sum(dim=0), f"counts {nodes[j].name}", True)
