@@ -120,7 +120,7 @@ inline void cpts_changed_fast(Plan& p) {
 // Tables for the fused tree iteration, if the plan qualifies (FastState::tree_ok).
 inline int prepare_tree(Plan& p, FastState& st) {
   st.tree_ok = false;
-  if (p.dtype != 0 || !st.wide.empty() || !st.fused.empty()) return 0;
+  if (!st.wide.empty() || !st.fused.empty()) return 0;
   auto dense = [](int32_t d) { return d == 32 || d == 64; };
   bool any = false;
   for (const FactorGroup& g : p.fgroups) {
@@ -195,15 +195,22 @@ inline bool launch_tree_iteration(Plan& p, size_t fi, int32_t gen, bool exact, h
   TreeFamilyTables tab{t.in_par[gen], t.in_own[gen], t.own_prev[gen], t.out[gen], g.d_cpt};
   const int32_t K = (int32_t)g.nodes.size();
   const dim3 grid((uint32_t)((int64_t)K * p.ntiles));
-  float* arena = static_cast<float*>(p.arena);
-  const float* cpts = static_cast<const float*>(p.cpts);
-  using Fn = void (*)(float*, const float*, TreeFamilyTables, int32_t, int64_t);
   const int32_t d0 = g.dims[0], sv = g.dims[1];
-  Fn fn = d0 == 64 ? (sv == 64 ? (exact ? factor_tree_mfma<64, 64, true> : factor_tree_mfma<64, 64, false>)
-                               : (exact ? factor_tree_mfma<64, 32, true> : factor_tree_mfma<64, 32, false>))
-                   : (sv == 64 ? (exact ? factor_tree_mfma<32, 64, true> : factor_tree_mfma<32, 64, false>)
-                               : (exact ? factor_tree_mfma<32, 32, true> : factor_tree_mfma<32, 32, false>));
-  launch(fn, grid, dim3(256), 0, s, arena, cpts, tab, K, p.ntiles);
+  if (p.dtype == 0) {
+    using Fn = void (*)(float*, const float*, TreeFamilyTables, int32_t, int64_t);
+    Fn fn = d0 == 64 ? (sv == 64 ? (exact ? factor_tree_mfma<64, 64, true> : factor_tree_mfma<64, 64, false>)
+                                 : (exact ? factor_tree_mfma<64, 32, true> : factor_tree_mfma<64, 32, false>))
+                     : (sv == 64 ? (exact ? factor_tree_mfma<32, 64, true> : factor_tree_mfma<32, 64, false>)
+                                 : (exact ? factor_tree_mfma<32, 32, true> : factor_tree_mfma<32, 32, false>));
+    launch(fn, grid, dim3(256), 0, s, static_cast<float*>(p.arena), static_cast<const float*>(p.cpts), tab, K, p.ntiles);
+  } else {
+    using Fn = void (*)(double*, const double*, TreeFamilyTables, int32_t, int64_t);
+    Fn fn = d0 == 64 ? (sv == 64 ? (exact ? factor_tree_mfma_f64<64, 64, true> : factor_tree_mfma_f64<64, 64, false>)
+                                 : (exact ? factor_tree_mfma_f64<64, 32, true> : factor_tree_mfma_f64<64, 32, false>))
+                     : (sv == 64 ? (exact ? factor_tree_mfma_f64<32, 64, true> : factor_tree_mfma_f64<32, 64, false>)
+                                 : (exact ? factor_tree_mfma_f64<32, 32, true> : factor_tree_mfma_f64<32, 32, false>));
+    launch(fn, grid, dim3(256), 0, s, static_cast<double*>(p.arena), static_cast<const double*>(p.cpts), tab, K, p.ntiles);
+  }
   return launch_ok();
 }
 

@@ -589,6 +589,136 @@ __global__ void __launch_bounds__(256) factor_p1_mfma_f64(double* __restrict__ a
   }
 }
 
+// u[ks] = product of the (one or two) arrays for state 4 * ks + kq and observation column `col` of
+// the 16-column block at `base`; inv = 1 / sum over the states of u (times the weight array's
+// entry, when there is one).  float64 twin of tree_operand.
+template <int KD>
+__device__ __forceinline__ void tree_operand_f64(const double* __restrict__ arena, int64_t first, int64_t second,
+                                                 int64_t weight, int64_t base, int32_t kq, int32_t col,
+                                                 double (&u)[KD / 4], double& inv) {
+  // 2^-exponent of the column's largest entry over all KD states (a lane holds every fourth state)
+  auto column_scale = [&](double mx) {
+    mx = fmax(mx, __shfl_xor(mx, 16, 64));
+    mx = fmax(mx, __shfl_xor(mx, 32, 64));
+    int e = 0;
+    (void)frexp(mx, &e);
+    return ldexp(1.0, mx > 0.0 ? -e : 0);
+  };
+  if (first == kNoArray) {
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 4; ++ks) u[ks] = 1.0;
+  } else {
+    const double* a0 = arena + first + base + kq * kTile64 + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 4; ++ks) u[ks] = a0[(int64_t)(4 * ks) * kTile64];
+    if (second != kNoArray) {
+      const double* a1 = arena + second + base + kq * kTile64 + col;
+      double v[KD / 4];
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 4; ++ks) v[ks] = a1[(int64_t)(4 * ks) * kTile64];
+      double mu = 0.0, mv = 0.0;
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 4; ++ks) {
+        mu = fmax(mu, u[ks]);
+        mv = fmax(mv, v[ks]);
+      }
+      const double su = column_scale(mu), sv = column_scale(mv);
+#pragma unroll
+      for (int32_t ks = 0; ks < KD / 4; ++ks) u[ks] = (u[ks] * su) * (v[ks] * sv);
+    }
+  }
+  double sum = 0.0;
+  if (weight != kNoArray) {
+    __builtin_amdgcn_sched_barrier(0);
+    const double* wgt = arena + weight + base + kq * kTile64 + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 4; ++ks) sum += u[ks] * wgt[(int64_t)(4 * ks) * kTile64];
+  } else {
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 4; ++ks) sum += u[ks];
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  inv = 1.0 / sum;
+}
+
+// factor_tree_mfma for float64 plans: same tables, same two contractions, on the float64 matrix
+// instruction with the operand layout of factor_p1_mfma_f64; a wave's 32 observations as two
+// blocks of 16 columns, one after the other.
+template <int D0, int S, bool EXACT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+factor_tree_mfma_f64(double* __restrict__ arena, const double* __restrict__ cpts, TreeFamilyTables tab, int32_t K,
+                     int64_t ntiles) {
+  __shared__ double w_lds[D0 * kCptPitch];
+  const int64_t item = blockIdx.x;
+  const int32_t k = (int32_t)(item / ntiles);
+  const int64_t t = item % ntiles;
+  if (k >= K) return;
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t kq = lane >> 4, col = lane & 15;
+
+  const double* cpt = cpts + tab.cpt_off[k];
+  for (int32_t e = threadIdx.x; e < D0 * S; e += 256) w_lds[(e / S) * kCptPitch + (e % S)] = cpt[e];
+  __syncthreads();
+  const int64_t in_par0 = tab.in_par[2 * k], in_par1 = tab.in_par[2 * k + 1];
+  const int64_t in_own0 = tab.in_own[2 * k], in_own1 = tab.in_own[2 * k + 1];
+  const int64_t own_prev = EXACT ? tab.own_prev[k] : kNoArray;
+  const int64_t out_par_off = tab.out[2 * k], out_own_off = tab.out[2 * k + 1];
+
+#pragma unroll 1
+  for (int32_t jt = 0; jt < 2; ++jt) {
+    const int32_t column = wave * 32 + 16 * jt;
+    // ---- to own variable
+    {
+      double u[D0 / 4], inv;
+      tree_operand_f64<D0>(arena, in_par0, in_par1, kNoArray, t * D0 * kTile64 + column, kq, col, u, inv);
+      __builtin_amdgcn_sched_barrier(0);
+      f64x4 acc[S / 16];
+#pragma unroll
+      for (int32_t it = 0; it < S / 16; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) acc[it][r] = 0.0;
+#pragma unroll
+      for (int32_t ks = 0; ks < D0 / 4; ++ks) {
+        const int32_t a = 4 * ks + kq;
+#pragma unroll
+        for (int32_t it = 0; it < S / 16; ++it)  // W[i=b][k=a] = cpt[a][b]
+          acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_lds[a * kCptPitch + 16 * it + col], u[ks], acc[it], 0, 0, 0);
+      }
+      double* out_own = arena + out_own_off + t * S * kTile64 + column + col;
+#pragma unroll
+      for (int32_t it = 0; it < S / 16; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) out_own[(int64_t)(16 * it + 4 * r + kq) * kTile64] = acc[it][r] * inv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- to parent
+    {
+      double u[S / 4], inv;
+      tree_operand_f64<S>(arena, in_own0, in_own1, own_prev, t * S * kTile64 + column, kq, col, u, inv);
+      __builtin_amdgcn_sched_barrier(0);
+      f64x4 acc[D0 / 16];
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 16; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) acc[it][r] = 0.0;
+#pragma unroll
+      for (int32_t ks = 0; ks < S / 4; ++ks) {
+        const int32_t b = 4 * ks + kq;
+#pragma unroll
+        for (int32_t it = 0; it < D0 / 16; ++it)  // W[i=a][k=b] = cpt[a][b]
+          acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_lds[(16 * it + col) * kCptPitch + b], u[ks], acc[it], 0, 0, 0);
+      }
+      double* out_par = arena + out_par_off + t * D0 * kTile64 + column + col;
+#pragma unroll
+      for (int32_t it = 0; it < D0 / 16; ++it)
+#pragma unroll
+        for (int32_t r = 0; r < 4; ++r) out_par[(int64_t)(16 * it + 4 * r + kq) * kTile64] = acc[it][r] * inv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // EM count matrix of the same families in float64: stat[a][b] = sum_n in_par[n][a] * in_own[n][b].
 // One workgroup per (node, chunk of tiles); 32 observations of both messages are staged in LDS
 // per step (pitch 33), each wave owns a quarter of the 16x16 output tiles.
