@@ -457,8 +457,30 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
   // factor messages and the normalisers that queries read); an even number of iterations in between
   // runs as one launch per factor group, each reading one generation of factor -> variable messages
   // and writing the other, so that the newest generation ends up in the usual arrays.
+  // When the messages are still fresh (uniform), the first iteration is such a launch too: its only
+  // inputs are the observation arrays.
   const int32_t tree_count = bn::tree_iterations_possible(p) && iterations >= 4 ? ((iterations - 2) & ~1) : 0;
   for (int32_t it = 0; it < iterations; ++it) {
+    if (it == 0 && tree_count > 0 && p.fresh) {
+      for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
+        bn::FactorGroup& g = p.fgroups[fi];
+        if (g.dims.size() == 1) {  // the prior message of a parentless node
+          prof_begin(flabel("factor_pass", g), factor_bytes(p, g, false), s);
+          if (bn::launch_factor_fast<T>(p, g, arena, cpts, 1, 1, 0, reduce_last, s, 0) <= 0)
+            return fail(BN_ERR_HIP, "launch of factor_root_fast failed");
+          prof_end(s);
+          continue;
+        }
+        prof_begin(flabel("tree_iteration_fresh", g),
+                   bn::fast_state(p)->tree.at((int32_t)fi).fresh_bytes_per_observation * (double)p.npad, s);
+        if (!bn::launch_tree_iteration(p, fi, bn::kTreeFresh, false, s))
+          return fail(BN_ERR_HIP, "launch of factor_tree_mfma failed");
+        prof_end(s);
+      }
+      p.fresh = false;  // every factor -> variable message has been written (the others by the last iteration)
+      bn::set_ingest_next(p, false);
+      continue;
+    }
     if (it >= 1 && it <= tree_count) {
       for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
         const bn::FactorGroup& g = p.fgroups[fi];

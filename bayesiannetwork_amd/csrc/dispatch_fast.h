@@ -70,7 +70,7 @@ inline void release_fast(Plan& p) {
     if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
   for (auto& kv : st->tree)
-    for (int32_t gen = 0; gen < 2; ++gen) {
+    for (int32_t gen = 0; gen < 3; ++gen) {
       if (kv.second.in_par[gen]) (void)hipFree(kv.second.in_par[gen]);
       if (kv.second.in_own[gen]) (void)hipFree(kv.second.in_own[gen]);
       if (kv.second.own_prev[gen]) (void)hipFree(kv.second.own_prev[gen]);
@@ -136,28 +136,31 @@ inline int prepare_tree(Plan& p, FastState& st) {
   };
   // messages a variable receives, except the one from factor `except_owner`
   auto others = [&](int32_t var, int32_t except_owner, int32_t gen, std::vector<int64_t>& out) {
-    if (except_owner != var) out.push_back(generation(p.edges[var], gen));
+    if (except_owner != var && gen != kTreeFresh) out.push_back(generation(p.edges[var], gen));
     for (int32_t child : p.children[var]) {
-      if (child == except_owner) continue;
+      if (child == except_owner || gen == kTreeFresh) continue;
       const auto& cp = p.parents[child];
       const int32_t pos = (int32_t)(std::find(cp.begin(), cp.end(), var) - cp.begin());
       out.push_back(generation(p.edges[p.parent_edge_base[child] + pos], gen));
     }
     if (p.observed_slot_of[var] >= 0) out.push_back(p.obs_off[p.observed_slot_of[var]]);
   };
-  std::map<int32_t, std::vector<int64_t>> host[2][4];  // [generation][in_par, in_own, own_prev, out]
+  std::map<int32_t, std::vector<int64_t>> host[3][4];  // [generation][in_par, in_own, own_prev, out]
   for (size_t fi = 0; fi < p.fgroups.size(); ++fi) {
     const FactorGroup& g = p.fgroups[fi];
     if (g.dims.size() != 2) continue;
-    double arrays = 0;
-    for (int32_t gen = 0; gen < 2; ++gen) {
+    double arrays = 0, fresh_arrays = 0;
+    for (int32_t gen = 0; gen < 3; ++gen) {
+      const int32_t to = gen == 0 ? 1 : 0;  // the generation this one writes
       for (int32_t j : g.nodes) {
         const int32_t parent = p.parents[j][0];
         std::vector<int64_t> par, own;
         others(parent, j, gen, par);
         others(j, j, gen, own);
-        if (par.empty() || par.size() > 2 || own.size() > 2) return 0;
-        if (gen == 0) arrays += (double)par.size() * g.dims[0] + (double)own.size() * g.dims[1] + g.dims[0] + g.dims[1];
+        if ((par.empty() && gen != kTreeFresh) || par.size() > 2 || own.size() > 2) return 0;
+        const double moved = (double)par.size() * g.dims[0] + (double)own.size() * g.dims[1] + g.dims[0] + g.dims[1];
+        if (gen == 0) arrays += moved;
+        if (gen == kTreeFresh) fresh_arrays += moved;
         par.resize(2, kNoArray);
         own.resize(2, kNoArray);
         const EdgeLayout& e_own = p.edges[j];
@@ -165,16 +168,17 @@ inline int prepare_tree(Plan& p, FastState& st) {
         auto& h = host[gen];
         h[0][(int32_t)fi].insert(h[0][(int32_t)fi].end(), par.begin(), par.end());
         h[1][(int32_t)fi].insert(h[1][(int32_t)fi].end(), own.begin(), own.end());
-        h[2][(int32_t)fi].push_back(generation(e_own, gen));
-        h[3][(int32_t)fi].push_back(generation(e_par, 1 - gen));
-        h[3][(int32_t)fi].push_back(generation(e_own, 1 - gen));
+        h[2][(int32_t)fi].push_back(generation(e_own, gen == kTreeFresh ? 0 : gen));  // not read when fresh
+        h[3][(int32_t)fi].push_back(generation(e_par, to));
+        h[3][(int32_t)fi].push_back(generation(e_own, to));
       }
     }
     st.tree[(int32_t)fi].bytes_per_observation = arrays * (double)p.elem_size;
+    st.tree[(int32_t)fi].fresh_bytes_per_observation = fresh_arrays * (double)p.elem_size;
     st.tree[(int32_t)fi].exact_bytes_per_observation = (double)g.nodes.size() * g.dims[1] * (double)p.elem_size;
   }
   for (auto& kv : st.tree) {
-    for (int32_t gen = 0; gen < 2; ++gen) {
+    for (int32_t gen = 0; gen < 3; ++gen) {
       if (!dev_upload(host[gen][0][kv.first], &kv.second.in_par[gen], p.device_bytes) ||
           !dev_upload(host[gen][1][kv.first], &kv.second.in_own[gen], p.device_bytes) ||
           !dev_upload(host[gen][2][kv.first], &kv.second.own_prev[gen], p.device_bytes) ||
@@ -186,8 +190,8 @@ inline int prepare_tree(Plan& p, FastState& st) {
   return 0;
 }
 
-// One fused flooding iteration of generation `gen` (0: f2v arrays -> v2f arrays, 1: back) for the
-// dense factor group fi.  Returns false on a launch failure.
+// One fused flooding iteration of generation `gen` (0: f2v arrays -> v2f arrays, 1: back,
+// kTreeFresh: uniform messages -> f2v arrays) for the dense factor group fi.  Returns false on a launch failure.
 inline bool launch_tree_iteration(Plan& p, size_t fi, int32_t gen, bool exact, hipStream_t s) {
   FastState* st = fast_state(p);
   const FactorGroup& g = p.fgroups[fi];

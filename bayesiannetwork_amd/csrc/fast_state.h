@@ -73,14 +73,18 @@ constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2;
 
 // Device tables of one dense factor group for the fused tree iteration (kernels_dense.h,
 // factor_tree_mfma), one set per generation: generation g reads the factor -> variable messages
-// from the f2v arrays (g = 0) or from the v2f arrays (g = 1) of the edges and writes the other.
+// from the f2v arrays (g = 0) or from the v2f arrays (g = 1) of the edges and writes the other;
+// set 2 is the first iteration on fresh messages (every message still uniform: only the
+// observation arrays are inputs) and writes the f2v arrays.
+constexpr int32_t kTreeFresh = 2;
 struct TreeGroupTables {
-  int64_t* in_par[2] = {nullptr, nullptr};
-  int64_t* in_own[2] = {nullptr, nullptr};
-  int64_t* own_prev[2] = {nullptr, nullptr};
-  int64_t* out[2] = {nullptr, nullptr};
+  int64_t* in_par[3] = {nullptr, nullptr, nullptr};
+  int64_t* in_own[3] = {nullptr, nullptr, nullptr};
+  int64_t* own_prev[3] = {nullptr, nullptr, nullptr};
+  int64_t* out[3] = {nullptr, nullptr, nullptr};
   double bytes_per_observation = 0;        // what one launch moves per observation (profiling)
   double exact_bytes_per_observation = 0;  // more for the launch that reads the own_prev arrays
+  double fresh_bytes_per_observation = 0;  // the first iteration on fresh messages
 };
 
 struct FastState {

@@ -166,6 +166,13 @@ __device__ __forceinline__ void tree_operand(const float* __restrict__ arena, in
     (void)frexpf(mx, &e);
     return ldexpf(1.0f, mx > 0.f ? -e : 0);
   };
+  // the weights travel together with the inputs (one memory round trip for all three arrays)
+  float w[KD / 2];
+  if (weight != kNoArray) {
+    const float* wgt = arena + weight + base + half * kTile + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 2; ++ks) w[ks] = wgt[(int64_t)(2 * ks) * kTile];
+  }
   if (first == kNoArray) {
 #pragma unroll
     for (int32_t ks = 0; ks < KD / 2; ++ks) u[ks] = 1.0f;
@@ -192,10 +199,8 @@ __device__ __forceinline__ void tree_operand(const float* __restrict__ arena, in
   }
   double sum = 0.0;
   if (weight != kNoArray) {
-    __builtin_amdgcn_sched_barrier(0);  // the weights' loads after the inputs' registers are free
-    const float* wgt = arena + weight + base + half * kTile + col;
 #pragma unroll
-    for (int32_t ks = 0; ks < KD / 2; ++ks) sum += (double)u[ks] * (double)wgt[(int64_t)(2 * ks) * kTile];
+    for (int32_t ks = 0; ks < KD / 2; ++ks) sum += (double)(u[ks] * w[ks]);
   } else {
 #pragma unroll
     for (int32_t ks = 0; ks < KD / 2; ++ks) sum += (double)u[ks];
@@ -210,7 +215,7 @@ __device__ __forceinline__ void tree_operand(const float* __restrict__ arena, in
 // survive the next normalisation, so only the last launch before a regular iteration (whose
 // normalisers the log-likelihood reads) has to be EXACT, and the others save reading one array.
 template <int D0, int S, bool EXACT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) factor_tree_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EXACT && D0 == 64 && S == 64 ? 2 : 3))) factor_tree_mfma(float* __restrict__ arena, const float* __restrict__ cpts,
                                                        TreeFamilyTables tab, int32_t K, int64_t ntiles) {
   __shared__ float w_lds[D0 * kCptPitch];
   const int64_t item = blockIdx.x;
@@ -604,6 +609,12 @@ __device__ __forceinline__ void tree_operand_f64(const double* __restrict__ aren
     (void)frexp(mx, &e);
     return ldexp(1.0, mx > 0.0 ? -e : 0);
   };
+  double w[KD / 4];
+  if (weight != kNoArray) {
+    const double* wgt = arena + weight + base + kq * kTile64 + col;
+#pragma unroll
+    for (int32_t ks = 0; ks < KD / 4; ++ks) w[ks] = wgt[(int64_t)(4 * ks) * kTile64];
+  }
   if (first == kNoArray) {
 #pragma unroll
     for (int32_t ks = 0; ks < KD / 4; ++ks) u[ks] = 1.0;
@@ -629,10 +640,8 @@ __device__ __forceinline__ void tree_operand_f64(const double* __restrict__ aren
   }
   double sum = 0.0;
   if (weight != kNoArray) {
-    __builtin_amdgcn_sched_barrier(0);
-    const double* wgt = arena + weight + base + kq * kTile64 + col;
 #pragma unroll
-    for (int32_t ks = 0; ks < KD / 4; ++ks) sum += u[ks] * wgt[(int64_t)(4 * ks) * kTile64];
+    for (int32_t ks = 0; ks < KD / 4; ++ks) sum += u[ks] * w[ks];
   } else {
 #pragma unroll
     for (int32_t ks = 0; ks < KD / 4; ++ks) sum += u[ks];

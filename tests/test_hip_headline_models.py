@@ -362,7 +362,7 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
     settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations)
     machine = HipSpaInferenceMachine(settings, network, observed, n)
     machine.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
-    # the route under test is the one taken: all but the first and the last one or two iterations
+    # the route under test is the one taken: all but the last one or two iterations
     from bayesiannetwork_amd.inference_machines.hip_spa.hip_spa_inference_machine import enable_profiling, profile_report
 
     enable_profiling(True)
@@ -374,7 +374,8 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
         enable_profiling(False)
     fused = sum(r["launches"] for r in report if r["kernel"].startswith("tree_iteration"))
     groups = len({r["kernel"] for r in report if r["kernel"].startswith("factor_pass[") and "x" in r["kernel"]})
-    assert groups == 4 and fused == groups * ((machine.num_iterations - 2) & ~1), report
+    fresh = sum(r["launches"] for r in report if r["kernel"].startswith("tree_iteration_fresh"))
+    assert groups == 4 and fresh == groups and fused - fresh == groups * ((machine.num_iterations - 2) & ~1), report
 
     _, network64, observed64 = _mixed_tree("cpu", "float64")
     for node64, node in zip(network64.nodes, network.nodes):
@@ -410,9 +411,26 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
             b = stepwise.message(node, owner, "f2v").double()
             assert torch.allclose(a, b, rtol=2e-5 if f32 else 1e-11, atol=1e-30), (node.name, owner.name)
 
+    want_counts = [oracle.infer_family(j).sum(dim=0) for j in range(len(nodes))]
+
+    # new evidence on the same machine: the iterations continue from the stored messages (no fresh
+    # first iteration), in the machine and in the oracle alike
+    again = []
+    for node in observed:
+        idx = torch.randint(0, node.num_states, (n,), generator=gen)
+        again.append((torch.nn.functional.one_hot(idx, node.num_states).double() * (1 - 1e-6)
+                      + 1e-6 / node.num_states).to(ts.dtype))
+    machine.enter_evidence(Evidence([e.cuda() for e in again], ts))
+    oracle.enter_evidence([e.double() for e in again])
+    want_again = oracle.log_likelihood(False)
+    assert abs(want_again - want_ll) > 1e-3 * abs(want_ll)  # a different answer, a hundred tolerances away
+    assert abs(machine.log_likelihood() - want_again) <= (1e-5 if f32 else 1e-9) * abs(want_again)
+    for node in nodes[:4]:
+        _check(machine.infer_single_nodes([node])[0], oracle.infer_single(index[node]), f"again: single {node.name}", f32)
+
     # the one-call statistics route (last iteration in reduce mode) on a second machine
     second = HipSpaInferenceMachine(settings, network, observed, n)
     ll2, flat2 = second.em_statistics(Evidence([e.cuda() for e in evidence], ts))
     assert abs(ll2.item() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
     for j, got in enumerate(second.split_counts(flat2)):
-        _check(got, oracle.infer_family(j).sum(dim=0), f"counts {nodes[j].name}", f32)
+        _check(got, want_counts[j], f"counts {nodes[j].name}", f32)
