@@ -443,6 +443,12 @@ int materialize(bn::Plan& p, hipStream_t s) {
   return rc;
 }
 
+// Set while bn_em_step runs its statistics: the plan's messages are reset right after the M-step, so
+// the factor -> variable messages of the last iteration (which neither the log-likelihood nor the
+// count sums read) are not computed.  Fused leaf families are exempt: their last launch IS the
+// statistics.
+thread_local bool t_discard_last_messages = false;
+
 template <typename T>
 int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t s) {
   T* arena = static_cast<T*>(p.arena);
@@ -524,6 +530,9 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
     p.c_stale = false;  // and every normaliser
     for (auto& g : p.fgroups) {
       const int32_t K = (int32_t)g.nodes.size();
+      if (t_discard_last_messages && reduce_last && it == iterations - 1 &&
+          !bn::is_fused_family_group(p, (size_t)(&g - p.fgroups.data())))
+        continue;
       {
         std::string label = flabel("factor_pass", g);
         double bytes = factor_bytes(p, g, false);
@@ -1651,7 +1660,10 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   int32_t ll_blocks = 0;
   const int rc = run_sequence(
       plan, key, num_iterations, s, &from_graph, &ll_blocks, [&](hipStream_t on, bool in_graph, int32_t* blocks) {
-        if (int rc2 = statistics_launches(p, num_iterations, 1, plan->accum_slot, on, blocks)) return rc2;
+        t_discard_last_messages = true;
+        const int rc2 = statistics_launches(p, num_iterations, 1, plan->accum_slot, on, blocks);
+        t_discard_last_messages = false;
+        if (rc2) return rc2;
         // M-step on the plan's own snapshot, in place; the caller's copy is written by the same kernel
         // unless the kernel runs from a graph (the caller's address may differ from call to call)
         const dim3 grid((uint32_t)((p.n_rows + 255) / 256));

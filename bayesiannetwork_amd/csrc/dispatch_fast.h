@@ -218,6 +218,11 @@ inline bool launch_tree_iteration(Plan& p, size_t fi, int32_t gen, bool exact, h
   return launch_ok();
 }
 
+inline bool is_fused_family_group(const Plan& p, size_t fi) {
+  FastState* st = fast_state(p);
+  return st && st->fused.count((int32_t)fi) != 0;
+}
+
 inline bool tree_iterations_possible(const Plan& p) {
   static const bool enabled = [] {
     const char* e = std::getenv("BN_TREE_FUSED");
