@@ -13,6 +13,7 @@ cd $R
 timeout -k 10 300 python3 bench.py > $OUT/${TAG}_bench_c3a_60k.json 2> $OUT/bench_c3a.err || { echo "bench failed"; tail -5 $OUT/bench_c3a.err; exit 1; }
 timeout -k 10 300 python3 bench.py --model c3b --no-cpu-baseline > $OUT/${TAG}_bench_c3b_60k.json 2> $OUT/bench_c3b.err || { echo "bench c3b failed"; exit 1; }
 timeout -k 10 300 python3 bench.py --model c5 --no-cpu-baseline > $OUT/${TAG}_bench_c5_131k.json 2> $OUT/bench_c5.err || { echo "bench c5 failed"; exit 1; }
+timeout -k 10 300 python3 bench.py --model c5 --dtype float64 --no-cpu-baseline > $OUT/${TAG}_bench_c5_131k_f64.json 2> $OUT/bench_c5_f64.err || { echo "bench c5 f64 failed"; exit 1; }
 # 2. rocprofv3 kernel trace + stats of the same default command
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/stats.log 2>&1 || { echo "rocprof stats failed"; tail -5 $OUT/stats.log; exit 1; }
