@@ -56,7 +56,12 @@ inline void release_fast(Plan& p) {
     if (w.d_chunk_first) (void)hipFree(w.d_chunk_first);
     if (w.part_mant) (void)hipFree(w.part_mant);
     if (w.part_exp) (void)hipFree(w.part_exp);
+    if (w.zdiv_mant[0]) (void)hipFree(w.zdiv_mant[0]);
+    if (w.zdiv_exp[0]) (void)hipFree(w.zdiv_exp[0]);
+    if (w.prod_mant) (void)hipFree(w.prod_mant);
+    if (w.prod_exp) (void)hipFree(w.prod_exp);
     if (w.scaled) (void)hipFree(w.scaled);
+    if (w.scaled_prev) (void)hipFree(w.scaled_prev);
   }
   for (auto& kv : st->fused) {
     if (kv.second.d_obs_off) (void)hipFree(kv.second.d_obs_off);
@@ -64,8 +69,6 @@ inline void release_fast(Plan& p) {
     if (kv.second.d_src) (void)hipFree(kv.second.d_src);
     if (kv.second.em_partial) (void)hipFree(kv.second.em_partial);
     if (kv.second.z_state) (void)hipFree(kv.second.z_state);
-    if (kv.second.zc_mant) (void)hipFree(kv.second.zc_mant);
-    if (kv.second.zc_exp) (void)hipFree(kv.second.zc_exp);
     if (kv.second.ll_part) (void)hipFree(kv.second.ll_part);
     if (kv.second.m_state) (void)hipFree(kv.second.m_state);
   }
@@ -84,7 +87,14 @@ inline void release_fast(Plan& p) {
 
 inline void invalidate_fast(Plan& p) {
   if (FastState* st = fast_state(p)) {
-    for (auto& w : st->wide) w.partials_valid = false;
+    for (auto& w : st->wide) {
+      w.partials_valid = false;
+      w.products_cached = false;
+      // nothing is carried over a reset: the alternating buffers start from the same side every time
+      // (a captured launch sequence holds their addresses)
+      w.zd_read = 0;
+      if (w.scaled > w.scaled_prev) std::swap(w.scaled, w.scaled_prev);
+    }
     for (auto& kv : st->fused) {
       kv.second.pending = false;
       kv.second.em_ready = false;
@@ -354,8 +364,7 @@ inline int prepare_fast(Plan& p) {
     auto it = st.fused.find(fi);
     if (it == st.fused.end()) return;
     FusedFamily& fam = it->second;
-    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, (void*)fam.d_src, fam.em_partial, fam.z_state, fam.m_state,
-                         (void*)fam.zc_mant, (void*)fam.zc_exp})
+    for (void* buffer : {(void*)fam.d_obs_off, (void*)fam.d_c_off, (void*)fam.d_src, fam.em_partial, fam.z_state, fam.m_state})
       if (buffer) (void)hipFree(buffer);
     for (int32_t j : p.fgroups[fi].nodes) handled[j] = 0;
     for (int32_t widx : {fam.wide_index, fam.wide_index2}) {
@@ -480,7 +489,27 @@ inline int prepare_fast(Plan& p) {
     if (hipMalloc(reinterpret_cast<void**>(&w.part_mant), rows * sizeof(double)) != hipSuccess) return -2;
     if (hipMalloc(reinterpret_cast<void**>(&w.part_exp), rows * sizeof(int32_t)) != hipSuccess) return -2;
     if (hipMalloc(reinterpret_cast<void**>(&w.scaled), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
-    p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 8);
+    if (hipMalloc(reinterpret_cast<void**>(&w.scaled_prev), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
+    p.device_bytes += (int64_t)(rows * 12 + (size_t)w.S * p.npad * 16);
+    if (w.fused_fgroup >= 0) {
+      // divisors of the chunk partial products: 1 until a loop launch of a one-parent group says otherwise
+      const size_t zd = (size_t)w.chunks * p.npad;
+      if (hipMalloc(reinterpret_cast<void**>(&w.zdiv_mant[0]), 2 * zd * sizeof(double)) != hipSuccess) return -2;
+      if (hipMalloc(reinterpret_cast<void**>(&w.zdiv_exp[0]), 2 * zd * sizeof(int32_t)) != hipSuccess) return -2;
+      w.zdiv_mant[1] = w.zdiv_mant[0] + zd;
+      w.zdiv_exp[1] = w.zdiv_exp[0] + zd;
+      p.device_bytes += (int64_t)(zd * 24);
+      wide_divisor_one<int32_t><<<dim3((uint32_t)std::min<size_t>(1024, (2 * zd + 255) / 256)), dim3(256), 0, 0>>>(
+          w.zdiv_mant[0], w.zdiv_exp[0], (int64_t)(2 * zd));
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return -2;
+      bool one_parent_only = true;
+      for (int32_t fi : w.fused_fgroups) one_parent_only = one_parent_only && st.fused[fi].wide_index2 < 0;
+      if (one_parent_only) {
+        if (hipMalloc(reinterpret_cast<void**>(&w.prod_mant), (size_t)w.S * p.npad * sizeof(double)) != hipSuccess) return -2;
+        if (hipMalloc(reinterpret_cast<void**>(&w.prod_exp), (size_t)w.S * p.npad * sizeof(int32_t)) != hipSuccess) return -2;
+        p.device_bytes += (int64_t)((size_t)w.S * p.npad * 12);
+      }
+    }
     for (int32_t fi : w.fused_fgroups) {
       FusedFamily& fam = st.fused[fi];
       if (fam.ll_part) continue;  // a two-parent group is visited from both its parents
@@ -489,12 +518,6 @@ inline int prepare_fast(Plan& p) {
       if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.ll_rows_cap * p.npad * sizeof(double)) != hipSuccess)
         return -2;
       p.device_bytes += (int64_t)((size_t)fam.ll_rows_cap * p.npad * sizeof(double));
-      if (fam.wide_index2 < 0) {
-        const size_t zc = (size_t)fam.chunks * p.npad;
-        if (hipMalloc(reinterpret_cast<void**>(&fam.zc_mant), zc * sizeof(double)) != hipSuccess) return -2;
-        if (hipMalloc(reinterpret_cast<void**>(&fam.zc_exp), zc * sizeof(int32_t)) != hipSuccess) return -2;
-        p.device_bytes += (int64_t)(zc * 12);
-      }
     }
   }
   if (int rc = prepare_tree(p, st)) return rc;
@@ -567,7 +590,12 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   a.n_uncovered = (int32_t)w.uncovered.size();
   a.part_mant = w.part_mant;
   a.part_exp = w.part_exp;
-  a.scaled = w.scaled;
+  a.zdiv_mant = w.zdiv_mant[w.zd_read];
+  a.zdiv_exp = w.zdiv_exp[w.zd_read];
+  a.prod_mant = w.prod_mant;
+  a.prod_exp = w.prod_exp;
+  a.prod_mode = (fresh || !w.prod_mant) ? 0 : (w.products_cached ? 2 : 1);
+  a.scaled = w.scaled_prev;  // the combine writes over the older of the two, then they swap
   a.npad = p.npad;
   a.ntiles = p.ntiles;
   a.fresh = fresh;
@@ -584,9 +612,17 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
 template <typename T, int S>
 inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, T* arena, int32_t fresh,
                              hipStream_t s) {
-  const WideArgs a = wide_args(p, g, w, fresh);
   const bool fused = w.fused_fgroup >= 0;
+  if (!fresh && (!fused || !w.partials_valid)) w.products_cached = false;  // the partial products are about to be rebuilt
+  const WideArgs a = wide_args(p, g, w, fresh);
   if (!fresh && (!fused || !w.partials_valid)) {
+    if (w.zdiv_mant[0]) {
+      // partial products rebuilt from the stored messages are complete
+      const int64_t zd = 2 * (int64_t)w.chunks * p.npad;
+      launch(wide_divisor_one<int32_t>, dim3((uint32_t)std::min<int64_t>(1024, (zd + 255) / 256)), dim3(256), 0, s,
+             w.zdiv_mant[0], w.zdiv_exp[0], zd);
+      if (!launch_ok()) return false;
+    }
     if constexpr (std::is_same<T, float>::value) {
       launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
       if (!launch_ok()) return false;
@@ -596,7 +632,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
       if (!launch_ok()) return false;
     }
   }
-  if (!fresh && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
+  if (!fresh && a.prod_mode != 2 && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
     // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
     const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
     if (lds > 48 * 1024 &&
@@ -606,11 +642,14 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
     launch(wide_combine_states<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
   } else {
     // waves per block: one per group of four chunks, none to spare while the messages are fresh
-    const int32_t nw = fresh ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
+    const int32_t nw = (fresh || a.prod_mode == 2) ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
     launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw),
            combine_lds_bytes<S>(nw), s, arena, a);
   }
   if (!launch_ok()) return false;
+  if (a.prod_mode == 1) w.products_cached = true;
+  std::swap(w.scaled, w.scaled_prev);
+  if (!fresh && w.zdiv_mant[0]) w.zd_read ^= 1;
   if (!fused) {
     if constexpr (std::is_same<T, float>::value) {
       launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
@@ -769,16 +808,17 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
   }
 }
 
-// w2: the second wide parent of a two-parent family group, nullptr for one-parent groups.  Defined
-// in dispatch_leaf.h and instantiated for float / double in translation units of their own.
+// w2: the second wide parent of a two-parent family group, nullptr for one-parent groups.
+// next_is_last: 0, or what the next iteration's launch will be: 1 a full launch, 2 a reduce launch.
+// Defined in dispatch_leaf.h and instantiated for float / double in translation units of their own.
 template <typename T>
 int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena, const T* cpts,
                        int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s, bool with_counts = true,
-                       bool next_is_last = false);
+                       int32_t next_is_last = 0);
 extern template int launch_leaf_family<float>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, float*, const float*,
-                                              int32_t, int32_t, int32_t, hipStream_t, bool, bool);
+                                              int32_t, int32_t, int32_t, hipStream_t, bool, int32_t);
 extern template int launch_leaf_family<double>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, double*,
-                                               const double*, int32_t, int32_t, int32_t, hipStream_t, bool, bool);
+                                               const double*, int32_t, int32_t, int32_t, hipStream_t, bool, int32_t);
 
 inline bool any_pending_fast(const Plan& p) {
   FastState* st = fast_state(p);
@@ -838,7 +878,12 @@ inline void append_state_signature(const Plan& p, std::string& key) {
   put(st->ingest_on);
   put(st->ingest_off);
   key.append(st->root_written.begin(), st->root_written.end());
-  for (const auto& w : st->wide) put(w.partials_valid);
+  for (const auto& w : st->wide) {
+    put(w.partials_valid);
+    put(w.products_cached);
+    put(w.zd_read);
+    put(w.scaled);  // which of its two buffers is the current one
+  }
   for (const auto& kv : st->fused) {
     const FusedFamily& fam = kv.second;
     put(fam.pending);
@@ -916,6 +961,8 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
 template <typename T>
 int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int32_t fresh, int32_t first_iteration,
                        int32_t last_iteration, int32_t reduce_last, hipStream_t s, int32_t next_is_last = 0) {
+  // next_is_last: this is the last but one iteration (told apart further below: 1 = a full launch follows, 2 = a reduce launch)
+  if (next_is_last) next_is_last = reduce_last ? 2 : 1;
   FastState* st = fast_state(p);
   const size_t fi = (size_t)(&g - p.fgroups.data());
   if (st) {
@@ -926,7 +973,7 @@ int launch_factor_fast(Plan& p, FactorGroup& g, T* arena_t, const T* cpts_t, int
       WideNode* w2 = it->second.wide_index2 >= 0 ? &st->wide[it->second.wide_index2] : nullptr;
       // reduce_last == 2: only the log-likelihood sums are wanted from the reduce-mode launch
       return launch_leaf_family<T>(p, g, it->second, w, w2, arena_t, cpts_t, fresh, first_iteration, mode, s,
-                                   reduce_last != 2, next_is_last != 0);
+                                   reduce_last != 2, next_is_last);
     }
   }
   {

@@ -37,17 +37,18 @@ struct LeafLoopKernel {
 template <typename T, int D0, int OUT, int STATE>
 inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s, bool split) {
   constexpr bool kFromCaller = STATE == kLoopIngest;
+  constexpr bool kLight = STATE == kLoopChunk;
   // blocks that share a chunk: instantiated for two-state leaves
   if (split)
     return s == 2 ? LeafLoopKernel<T>{leaf_loop_p1<T, D0, 2, OUT, STATE, true>,
-                                      (size_t)kWavesPerBlock * LeafRing<T, 2, kFromCaller>::kWaveBytes}
+                                      (size_t)kWavesPerBlock * LeafRing<T, 2, kFromCaller, kLight>::kWaveBytes}
                   : LeafLoopKernel<T>{};
   switch (s) {
 #define X(SV)                                                                                       \
   case SV:                                                                                          \
     if constexpr (SV == 2 || (STATE != kLoopIngest && STATE != kLoopIngestStates))                  \
       return {leaf_loop_p1<T, D0, SV, OUT, STATE>,                                                  \
-              (size_t)kWavesPerBlock * LeafRing<T, SV, kFromCaller>::kWaveBytes};                   \
+              (size_t)kWavesPerBlock * LeafRing<T, SV, kFromCaller, kLight>::kWaveBytes};           \
     break;
     BN_SMALL_DIMS(X)
 #undef X
@@ -96,28 +97,47 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
 template <typename T>
 int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena, const T* cpts,
                        int32_t fresh, int32_t first_iteration, int32_t mode, hipStream_t s, bool with_counts,
-                       bool next_is_last) {
-  const int32_t state = fresh ? kLeafFresh : (first_iteration ? kLeafFromArrays : kLeafSteady);
+                       int32_t next_is_last) {
+  // One-parent groups: the loop launch of the last but one iteration is left out when a reduce launch
+  // follows and this iteration continues from loop state: all it would leave is one z per family,
+  // and the reduce launch forms those again from the parent's two scaled products (kLeafRecompute).
+  if (mode == kLeafLoop && !w2 && next_is_last == 2 && !fresh && !first_iteration && fam.z_form == kZPerChunk &&
+      !env_no_recompute()) {
+    fam.z_form = kZRecompute;
+    fam.pending = false;
+    fam.em_ready = false;
+    return 1;
+  }
+  const int32_t state = fresh ? kLeafFresh
+                              : (first_iteration ? kLeafFromArrays : (fam.z_form == kZRecompute ? kLeafRecompute : kLeafSteady));
   const bool ingest_wanted = fresh && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next;
   LeafFamilyFn<T> fn = nullptr;
   size_t lds_bytes = 0;
   const bool loop_p1 = mode == kLeafLoop && !w2;
   int32_t loop_out = kLoopLight;
+  bool split = false;  // loop_p1 only: the waves of a block share one (chunk, tile, part) work item
+  bool light = false;  // ... and the launch carries no per-state product
   if (loop_p1) {
     // one-parent loop launch: the launch before a full / reduce launch leaves one z per family,
     // any earlier one the chunk products of the z
     loop_out = next_is_last ? kLoopLast : kLoopLight;
+    if (state == kLeafRecompute) return -1;  // no loop launch continues from there
     int32_t from = fresh ? kLoopFresh : (first_iteration ? kLoopFromArrays : kLoopChunk);
     if (ingest_wanted) {
       if (loop_out != kLoopLight) return -1;  // callers ask for ingestion only with a loop launch to spare
       from = fast_state(p)->ingest_states ? kLoopIngestStates : kLoopIngest;
     }
     if (from == kLoopChunk && fam.z_form != kZPerChunk) return -1;
+    // A launch that carries no per-state product needs half the registers: the waves of a block then
+    // share a chunk at every batch size (four times the waves, each a quarter as long, six to
+    // seven of them resident per SIMD instead of four).
+    light = from == kLoopChunk;
+    split = fam.split > 1 || (from == kLoopChunk && g.dims[1] == 2 && !env_no_light_split());
     LeafLoopKernel<T> k;
     switch (loop_out * 8 + from) {
 #define X(OUT, FROM)                                                      \
   case OUT * 8 + FROM:                                                    \
-    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1], fam.split > 1); \
+    k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1], split); \
     break;
       X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
       X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates)
@@ -148,7 +168,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   case M:    \
     fn = leaf_family_lookup<T, M>(g.dims[0], g.dims[1]); \
     break;
-      X(1) X(2) X(4) X(5) X(7) X(8)
+      X(1) X(2) X(4) X(5) X(7) X(8) X(10) X(11)
 #undef X
     }
   }
@@ -164,6 +184,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
         case kLeafSteady: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafSteady>(g.dims[0]); break;
         case kLeafFresh: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFresh>(g.dims[0]); break;
         case kLeafFromArrays: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFromArrays>(g.dims[0]); break;
+        case kLeafRecompute: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafRecompute>(g.dims[0]); break;
       }
       if (fn4) {
         // 140 VGPRs, three waves per SIMD: one round of resident waves (3 x 1024) per launch
@@ -189,13 +210,16 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   a.chunk_base = fam.chunk_base;
   a.part_mant = w.part_mant;
   a.part_exp = w.part_exp;
+  a.zdiv_mant = w.zdiv_mant[w.zd_read];
+  a.zdiv_exp = w.zdiv_exp[w.zd_read];
+  a.zdiv_next_mant = w.zdiv_mant[w.zd_read ^ 1];
+  a.zdiv_next_exp = w.zdiv_exp[w.zd_read ^ 1];
   a.scaled = w.scaled;
+  a.scaled_prev = w.scaled_prev;
   a.npad = p.npad;
   a.ntiles = p.ntiles;
   a.N = p.N;
   a.z_state = static_cast<T*>(fam.z_state);
-  a.zc_mant = fam.zc_mant;
-  a.zc_exp = fam.zc_exp;
   a.em_partial = with_counts ? static_cast<T*>(fam.em_partial) : nullptr;
   a.slots = fam.slots;
   a.ll_part = fam.ll_part;
@@ -206,12 +230,21 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   a.src = fam.d_src;
   a.on_value = (T)fast_state(p)->ingest_on;
   a.off_value = (T)fast_state(p)->ingest_off;
-  a.split = loop_p1 ? fam.split : 1;
+  a.split = split ? kWavesPerBlock : 1;
   int64_t waves = (int64_t)fam.chunks * p.ntiles * leaf_parts(p);
   if (a.split > 1) {
-    // one block per work item, and room for the quarters' products to meet (after the rings)
+    // one block per work item, and room for the quarters' products to meet (after the rings; a
+    // launch without the per-state product reuses the rings)
     waves *= kWavesPerBlock;
-    lds_bytes += (size_t)(kWavesPerBlock - 1) * (g.dims[0] * 2 + 4) * 64 * (sizeof(double) + sizeof(int32_t));
+    if (!light) lds_bytes += (size_t)(kWavesPerBlock - 1) * (g.dims[0] * 2 + 4) * 64 * (sizeof(double) + sizeof(int32_t));
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess)
+      return -1;
+  }
+  if (!loop_p1 && !w2 && state == kLeafRecompute) {
+    // the previous iteration's scaled product of the wave's observations, per lane
+    lds_bytes = (size_t)kWavesPerBlock * g.dims[0] * 64 * (wide4 ? 4 : kLeafVec) * sizeof(T);
     if (lds_bytes > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes) != hipSuccess)
@@ -239,6 +272,11 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     fam.em_ready = false;
     w.partials_valid = true;
     if (w2) w2->partials_valid = true;
+    // every launch but a loop launch without the per-state product rewrote its chunks' partial products
+    if (!light) {
+      w.products_cached = false;
+      if (w2) w2->products_cached = false;
+    }
   }
   return 1;
 }

@@ -31,7 +31,22 @@ struct WideNode {
   int32_t* d_chunk_first = nullptr;  // [chunks + 1] chunk boundaries in `covered`
   double* part_mant = nullptr;
   int32_t* part_exp = nullptr;
+  // P' of the last combine and of the one before (the combine writes over the older one and the two
+  // swap; a reduce launch that recomputes the leaves' normalisers reads both)
   double* scaled = nullptr;
+  double* scaled_prev = nullptr;
+  // fused nodes: per chunk and observation, what the combine divides the chunk's partial product by.
+  // Two arrays that alternate: the next combine reads zdiv_*[zd_read], the one after it the other
+  // (see kernels_leaf_loop.h); every combine on stored state flips zd_read.
+  double* zdiv_mant[2] = {nullptr, nullptr};  // [chunks][npad] each, one allocation
+  int32_t* zdiv_exp[2] = {nullptr, nullptr};
+  int32_t zd_read = 0;
+  // the product over all chunk partials, per state (mantissa, exponent), kept from the first combine
+  // after they were written for the combines that follow while they stay the same (loop launches
+  // that only move the divisors); only for nodes whose fused groups are all one-parent groups
+  double* prod_mant = nullptr;  // [S][npad]
+  int32_t* prod_exp = nullptr;  // [S][npad]
+  bool products_cached = false;
   bool partials_valid = false;
   // some covered / uncovered slot's message arrays lie in the plan's lazy region
   bool covered_lazy = false, uncovered_lazy = false;
@@ -50,11 +65,11 @@ struct FusedFamily {
   const void** d_src = nullptr;    // [K] evidence source of each leaf for an ingesting launch
   std::vector<const void*> src_on_device;  // what d_src holds
   void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
-  // chunk products of the normalisers: the state between two loop launches of a one-parent group
-  double* zc_mant = nullptr;    // [chunks][npad]
-  int32_t* zc_exp = nullptr;    // [chunks][npad]
-  // which of the two the last loop launch wrote: kZPerFamily (z_state; what full / reduce launches
-  // read), kZPerChunk (zc_*; what the next loop launch reads), kZNone after a reset
+  // where the leaves' normalisers of the coming iteration are: kZPerFamily (z_state, written by a
+  // loop launch that a full launch follows), kZPerChunk (only their chunk products, in the parent's
+  // divisor arrays: what loop launches need), kZRecompute (as kZPerChunk, and the loop launch of the
+  // last but one iteration was left out: the reduce launch forms them again from the parent's two
+  // scaled products), kZNone after a reset
   int32_t z_form = 0;
   void* em_partial = nullptr;   // [K][entries][slots] (plan's element type), written by the reduce-mode kernel
   int32_t slots = 0;
@@ -69,7 +84,7 @@ struct FusedFamily {
   bool em_ready = false;  // em_partial holds the counts of the current state
 };
 
-constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2;
+constexpr int32_t kZNone = 0, kZPerFamily = 1, kZPerChunk = 2, kZRecompute = 3;
 
 // Device tables of one dense factor group for the fused tree iteration (kernels_dense.h,
 // factor_tree_mfma), one set per generation: generation g reads the factor -> variable messages
@@ -146,6 +161,16 @@ inline int32_t env_share_max() {
 }
 inline int32_t env_combine_states_max() {
   static const int32_t v = getenv("BN_COMBINE_STATES_MAX") ? env_int("BN_COMBINE_STATES_MAX") : (1 << 30);
+  return v;
+}
+// BN_NO_LIGHT_SPLIT=1  loop launches without the per-state product run one wave per chunk like the others
+inline bool env_no_light_split() {
+  static const bool v = getenv("BN_NO_LIGHT_SPLIT") != nullptr;
+  return v;
+}
+// BN_NO_RECOMPUTE=1  the loop launch before a reduce launch always runs (and stores the leaves' normalisers)
+inline bool env_no_recompute() {
+  static const bool v = getenv("BN_NO_RECOMPUTE") != nullptr;
   return v;
 }
 inline bool env_reduce_v2() {

@@ -20,14 +20,18 @@ struct LeafFamilyArgs {
   int32_t chunk_base;         // where they sit among the parent's chunk partials
   double* part_mant;
   int32_t* part_exp;
+  // what the parent's combine divides each chunk's partial product by, per observation (mantissa in
+  // [0.5, 1) and exponent): loop launches keep prod_k z_k here and leave it out of the partial
+  // product, a full launch writes 1
+  double* zdiv_mant;   // [parent's chunks][npad]  the array the parent's next combine reads
+  int32_t* zdiv_exp;   // [parent's chunks][npad]
+  double* zdiv_next_mant;  // the array the combine after that reads
+  int32_t* zdiv_next_exp;
+  const double* scaled_prev;  // parent's P' of the previous iteration (kLeafRecompute)
   const double* scaled;  // parent's P'
   int64_t npad;
   int64_t ntiles;
   T* z_state;  // [K][npad] loop state: the leaf's normaliser z for the coming iteration
-  // loop state between two loop launches (leaf_loop_p1): prod_k z_k over each chunk's families,
-  // per observation, as mantissa in [0.5, 1) and exponent
-  double* zc_mant;   // [chunks][npad]
-  int32_t* zc_exp;   // [chunks][npad]
   // kLeafReduce only
   int64_t N;
   T* em_partial;  // [K][D0*S][slots] per-wave sums of (message from parent) x (message from own variable); nullptr = not wanted
@@ -62,8 +66,17 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 // kernel's MODE template argument as MODE = mode + 3 * state):
 //   kLeafSteady      the loop state a kLeafLoop launch left (z_state);
 //   kLeafFresh       nothing has been sent yet: every message still has its initial uniform value;
-//   kLeafFromArrays  the message arrays a kLeafFull launch wrote.
-constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2;
+//   kLeafFromArrays  the message arrays a kLeafFull launch wrote;
+//   kLeafRecompute   like kLeafSteady, but the leaves' normalisers are not read: z = sum(P'prev) /
+//                    sum(P'prev / q) is formed again from the parent's scaled product of the previous
+//                    iteration (exactly what the loop launch of that iteration would have stored),
+//                    so that launch does not have to run at all.  P'prev is kept in LDS, per lane.
+constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafRecompute = 3;
+// dynamic LDS of a kLeafRecompute launch
+template <typename T, int D0, int V>
+constexpr size_t leaf_recompute_lds_bytes() {
+  return (size_t)kWavesPerBlock * D0 * 64 * V * sizeof(T);
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -207,7 +220,9 @@ __device__ __forceinline__ LeafState<T, S, V> leaf_state(const LeafPtrs<T>& p, c
   LeafState<T, S, V> st;
 #pragma unroll
   for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
-  if constexpr (STATE != kLeafSteady) {
+  if constexpr (STATE == kLeafRecompute) {
+    st.z = splat<T, V>((T)1);  // formed in the family loop
+  } else if constexpr (STATE != kLeafSteady) {
     fv<T, V> own[S];
 #pragma unroll
     for (int32_t j = 0; j < S; ++j)
@@ -284,6 +299,22 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     }
   }
 
+  // kLeafRecompute: the previous iteration's P' for this lane's observations, in LDS
+  extern __shared__ __align__(16) unsigned char recompute_raw[];
+  fv<T, V>* prev_pf = reinterpret_cast<fv<T, V>*>(recompute_raw) + (size_t)wave * D0 * 64 + lane;  // [D0] stride 64
+  fv<T, V> prev_sum = splat<T, V>((T)0);
+  if constexpr (STATE == kLeafRecompute) {
+    const double* scaled = a.scaled_prev + t * tile_of<T>::value + col;
+#pragma unroll
+    for (int32_t i = 0; i < D0; ++i) {
+      fv<T, V> x;
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) x[v] = (T)scaled[(int64_t)i * a.npad + v];
+      prev_pf[i * 64] = x;
+      prev_sum = i == 0 ? x : prev_sum + x;
+    }
+  }
+
   // reduce mode: prod_k z_k per observation (one log at the end gives sum_k log z_k)
   double pz[V];
   int32_t pze[V];
@@ -314,18 +345,34 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     // parent's message to this factor, before normalisation: r = P' / (previous message to the parent)
     fv<T, V> r[D0];
     fv<T, V> inv_sum = splat<T, V>(0.f);
+    if constexpr (STATE == kLeafRecompute) {
+      // the same operations, in the same order, as the loop launch's z' = sum(P') / sum(P' / q)
+      fv<T, V> sum_r = splat<T, V>(0.f);
+      // read again for every family (held in registers over the loop, P'prev would cost a wave per SIMD)
+      const fv<T, V>* prev_here = prev_pf;
+      asm volatile("" : "+v"(prev_here));
 #pragma unroll
-    for (int32_t i = 0; i < D0; ++i) {
-      fv<T, V> prev;
-      if constexpr (STATE == kLeafFresh) {
-        prev = splat<T, V>(1.0f / (T)D0);
-      } else if constexpr (STATE == kLeafFromArrays) {
-        prev = loadv<T, V>(ptr.f2v_par, t * D0 + i, col);
-      } else {
-        prev = q[i];
+      for (int32_t i = 0; i < D0; ++i) {
+        const fv<T, V> rq = rcpv<T, V>(q[i]);
+        sum_r = __builtin_elementwise_fma(prev_here[i * 64], rq, sum_r);
+        r[i] = pf[i] * rq;
+        inv_sum += r[i];
       }
-      r[i] = pf[i] * rcpv<T, V>(prev);
-      inv_sum += r[i];
+      cur.z = prev_sum * rcpv<T, V>(sum_r);
+    } else {
+#pragma unroll
+      for (int32_t i = 0; i < D0; ++i) {
+        fv<T, V> prev;
+        if constexpr (STATE == kLeafFresh) {
+          prev = splat<T, V>(1.0f / (T)D0);
+        } else if constexpr (STATE == kLeafFromArrays) {
+          prev = loadv<T, V>(ptr.f2v_par, t * D0 + i, col);
+        } else {
+          prev = q[i];
+        }
+        r[i] = pf[i] * rcpv<T, V>(prev);
+        inv_sum += r[i];
+      }
     }
     inv_sum = rcpv<T, V>(inv_sum);
     if constexpr (REDUCE) {
@@ -446,12 +493,14 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     }
     return;
   }
-  double inv_pz[V];
+  // the partial product holds the whole messages (q / z): nothing is left for the combine to divide by
 #pragma unroll
   for (int32_t v = 0; v < V; ++v) {
-    int de = 0;
-    inv_pz[v] = 1.0 / frexp(pz[v], &de);  // pz stayed 1 in full mode
-    pze[v] += de;
+    const int64_t at = (int64_t)(a.chunk_base + chunk) * a.npad + t * tile_of<T>::value + col + v;
+    a.zdiv_mant[at] = 0.5;
+    a.zdiv_exp[at] = 1;
+    a.zdiv_next_mant[at] = 0.5;
+    a.zdiv_next_exp[at] = 1;
   }
 #pragma unroll
   for (int32_t s = 0; s < D0; ++s) {
@@ -459,8 +508,8 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {
       int de = 0;
-      pm[s][v] = frexp(pm[s][v] * inv_pz[v], &de);
-      ex[v] = (int32_t)pe[s][v] + de - pze[v];
+      pm[s][v] = frexp(pm[s][v], &de);
+      ex[v] = (int32_t)pe[s][v] + de;
     }
     const int64_t row = ((int64_t)(a.chunk_base + chunk) * D0 + s) * a.npad + t * tile_of<T>::value + col;
     if constexpr (V == 4) {

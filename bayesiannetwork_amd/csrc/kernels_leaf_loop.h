@@ -8,10 +8,17 @@
 //     holding registers, so HBM latency hides behind the arithmetic at four waves per SIMD.
 //   * Per-family table entries and CPT rows are read with scalar loads one family ahead.
 //   * The leaves' normalisers z_k are only needed as their product over the chunk (it scales the
-//     parent's partial product).  A launch that is followed by another loop launch (kLoopLight)
-//     therefore writes prod_k z_k per (chunk, observation) - mantissa and exponent - instead of
-//     one z per family and observation; only the launch before a full / reduce launch
-//     (kLoopLast) writes every z, which those kernels read.
+//     parent's partial product).  The chunk's partial product of the messages to the parent is
+//     prod_k q_k[s] / prod_k z_k with q_k = cpt_k . ev_k.  The numerator does not change from one
+//     iteration of a call to the next (same CPTs, same evidence), so only the call's first loop
+//     launch forms it (per state, double mantissa and exponent) and writes it to the partial-product
+//     array; the denominators go to the parent's two divisor arrays (LeafFamilyArgs::zdiv_*), which
+//     alternate: the launch of iteration t leaves prod z of iteration t + 1 in the array the combine
+//     of iteration t has just read (the first launch also writes that of its own iteration into the
+//     other one), and the combine divides.  Later launches carry no per-state product at all and
+//     read nothing but the evidence and the parent's scaled product.
+//   * Only a launch that a full launch follows (kLoopLast) writes one z per family and observation,
+//     which that kernel reads; a reduce launch recomputes them (kLeafRecompute).
 #pragma once
 
 #include "kernels_leaf.h"
@@ -20,7 +27,8 @@ namespace bn {
 
 constexpr int32_t kLoopLight = 0, kLoopLast = 1;
 // where the iteration's input state comes from
-//   kLoopChunk         a kLoopLight launch: chunk products of the normalisers (zc_mant / zc_exp)
+//   kLoopChunk         an earlier loop launch of the same call (nothing is read: the state is in the
+//                      parent's divisor arrays)
 //   kLoopFresh         nothing has been sent yet (uniform messages)
 //   kLoopFromArrays    the message arrays a full launch wrote
 //   kLoopIngest        as kLoopFresh, evidence read from the caller's [N][2] arrays and copied into
@@ -62,13 +70,23 @@ __device__ __forceinline__ int32_t frexp_in_place(double& x) {
 }
 
 // Geometry of the evidence ring for element type T and S states (two observations per lane).
-template <typename T, int S, bool FROM_CALLER>
+// LIGHT: the launch carries no per-state product (STATE == kLoopChunk): it runs with half the
+// registers, so twice the waves are resident and each needs half as many families in flight.
+template <typename T, int S, bool FROM_CALLER, bool LIGHT = false>
 struct LeafRing {
   static constexpr int32_t kRowBytes = 64 * 2 * (int32_t)sizeof(T);        // one state row of the wave's observations
   static constexpr int32_t kFamilyBytes = S * kRowBytes;                    // the same bytes in the caller's [N][S] layout
   static constexpr int32_t kDmas = (kFamilyBytes + 1023) / 1024;            // DMA instructions per family
   static constexpr int32_t kSlotBytes = kDmas * 1024;
-  static constexpr int32_t kDepth = 8192 / kSlotBytes >= 8 ? 8 : (8192 / kSlotBytes >= 2 ? 8192 / kSlotBytes : 2);
+#ifdef BN_X_DEPTH
+  static constexpr int32_t kBudget = LIGHT ? BN_X_DEPTH * 1024 : 8192;
+  static constexpr int32_t kMaxDepth = LIGHT ? BN_X_DEPTH : 8;
+#else
+  static constexpr int32_t kBudget = LIGHT ? 4096 : 8192;
+  static constexpr int32_t kMaxDepth = LIGHT ? 4 : 8;
+#endif
+  static constexpr int32_t kDepth =
+      kBudget / kSlotBytes >= kMaxDepth ? kMaxDepth : (kBudget / kSlotBytes >= 2 ? kBudget / kSlotBytes : 2);
   static constexpr int32_t kWaveBytes = kDepth * kSlotBytes;
 };
 
@@ -82,8 +100,10 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   constexpr bool LAST = OUT == kLoopLast;
   constexpr bool INGEST = STATE == kLoopIngest, INGEST_STATES = STATE == kLoopIngestStates;
   constexpr bool FRESH = STATE == kLoopFresh || INGEST || INGEST_STATES;
+  // the first loop launch of a call forms prod q per state; the others reuse what it wrote
+  constexpr bool PROD = STATE != kLoopChunk;
   static_assert(!(INGEST || INGEST_STATES) || S == 2, "evidence is taken from the caller's arrays for two-state leaves only");
-  using Ring = LeafRing<T, S, INGEST>;
+  using Ring = LeafRing<T, S, INGEST, STATE == kLoopChunk>;
   constexpr int32_t R = Ring::kDepth, ND = Ring::kDmas;
   // vector-memory operations issued per family besides the DMAs (they sit between the DMAs in the
   // queue, so the counted waits allow for them): the z store of kLoopLast, the arena copy of the
@@ -206,14 +226,6 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   // prod_k z_k of this iteration (read, or multiplied up below) and of the next one
   double zin_m[V] = {1.0, 1.0};
   int32_t zin_e[V] = {0, 0};
-  if (STATE == kLoopChunk && !(split && wave > 0)) {
-    const double2 m = *reinterpret_cast<const double2*>(a.zc_mant + (int64_t)chunk * a.npad + obs0);
-    const int2 e = *reinterpret_cast<const int2*>(a.zc_exp + (int64_t)chunk * a.npad + obs0);
-    zin_m[0] = m.x;
-    zin_m[1] = m.y;
-    zin_e[0] = e.x;
-    zin_e[1] = e.y;
-  }
   double pz[V] = {1.0, 1.0};
   int32_t pze[V] = {0, 0};
 
@@ -260,7 +272,11 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     if constexpr (INGEST_STATES) {
       nxt_pair = states_pair(first + in);
     } else {
+#ifdef BN_X_NODMA
+      if (false) {
+#else
       if (i + R < n) {
+#endif
         // the slot of family i is free once its evidence is in registers
 #pragma unroll
         for (int32_t j = 0; j < S; ++j) asm volatile("" ::"v"(cur_ev[j]));
@@ -310,6 +326,11 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     // the leaf's next normaliser z' = sum_i t_i q_i with t = r / sum r, r = P' / (previous message
     // to the parent); in the steady state r = P' / q and z' = sum(P') / sum(r)
     fv<T, V> zn;
+#ifdef BN_X_NOCOMPUTE
+    if constexpr (STATE == kLoopChunk) {
+      zn = cur_ev[0] + cur_ev[1];
+    } else
+#endif
     if constexpr (STATE == kLoopChunk) {
       fv<T, V> sum_r = splat<T, V>(0.f);
 #pragma unroll
@@ -329,18 +350,22 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     if constexpr (LAST) storev<T, V>(a.z_state + (int64_t)k * a.npad, t, col, zn);
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {
+      if constexpr (PROD) {
 #pragma unroll
-      for (int32_t d = 0; d < D0; ++d) pm[d][v] *= (double)q[d][v];
+        for (int32_t d = 0; d < D0; ++d) pm[d][v] *= (double)q[d][v];
+      }
       if constexpr (!LAST) pz[v] *= (double)zn[v];
     }
     if (--until_renorm == 0) {
       until_renorm = sizeof(T) == 8 ? 1 : 6;
+      if constexpr (PROD) {
 #pragma unroll
-      for (int32_t d = 0; d < D0; ++d) {
-        ev_t<V> de_v;
+        for (int32_t d = 0; d < D0; ++d) {
+          ev_t<V> de_v;
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) de_v[v] = frexp_in_place(pm[d][v]);
-        pe[d] += de_v;
+          for (int32_t v = 0; v < V; ++v) de_v[v] = frexp_in_place(pm[d][v]);
+          pe[d] += de_v;
+        }
       }
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
@@ -358,24 +383,38 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     for (int32_t j = 0; j < E; ++j) cpt_cur[j] = cpt_nxt[j];
   }
   if constexpr (SPLIT) {
-    // the four quarters' products meet in wave 0 (every factor brought to [0.5, 1) first)
-    double* mm = reinterpret_cast<double*>(ring_raw + kWavesPerBlock * Ring::kWaveBytes);
-    constexpr int32_t kDoubles = D0 * V + 2 * V, kInts = D0 * V + 2 * V;
-    int32_t* me = reinterpret_cast<int32_t*>(mm + (size_t)(kWavesPerBlock - 1) * kDoubles * 64);
+    // the four quarters' products meet in wave 0 (every factor brought to [0.5, 1) first).  With the
+    // per-state product they need room of their own after the rings; without it they fit into the
+    // ring of the wave that writes them, which it has finished reading by then.
+    constexpr int32_t kDoubles = PROD ? D0 * V + 2 * V : V, kInts = kDoubles;
+    static_assert(PROD || kDoubles * 64 * 12 <= Ring::kWaveBytes, "a wave's record does not fit into its ring");
+    auto record_m = [&](int32_t wv) -> double* {  // wave wv's mantissas (wv = 1..)
+      if constexpr (PROD)
+        return reinterpret_cast<double*>(ring_raw + kWavesPerBlock * Ring::kWaveBytes) + (size_t)(wv - 1) * kDoubles * 64;
+      return reinterpret_cast<double*>(ring_raw + wv * Ring::kWaveBytes);
+    };
+    auto record_e = [&](int32_t wv) -> int32_t* {
+      if constexpr (PROD)
+        return reinterpret_cast<int32_t*>(record_m(kWavesPerBlock)) + (size_t)(wv - 1) * kInts * 64;
+      return reinterpret_cast<int32_t*>(record_m(wv) + kDoubles * 64);
+    };
+    constexpr int32_t kZ = PROD ? D0 * V : 0;  // where the z products start in a wave's record
+    if constexpr (PROD) {
 #pragma unroll
-    for (int32_t d = 0; d < D0; ++d)
+      for (int32_t d = 0; d < D0; ++d)
 #pragma unroll
-      for (int32_t v = 0; v < V; ++v) {
-        pe[d][v] += (short)frexp_in_place(pm[d][v]);
-        if (spare) {
-          pm[d][v] = 0.5;
-          pe[d][v] = 1;
+        for (int32_t v = 0; v < V; ++v) {
+          pe[d][v] += (short)frexp_in_place(pm[d][v]);
+          if (spare) {
+            pm[d][v] = 0.5;
+            pe[d][v] = 1;
+          }
         }
-      }
+    }
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {
       pze[v] += frexp_in_place(pz[v]);
-      if (STATE != kLoopChunk || wave == 0) zin_e[v] += frexp_in_place(zin_m[v]);
+      if constexpr (PROD) zin_e[v] += frexp_in_place(zin_m[v]);
       if (spare) {
         pz[v] = 0.5;
         pze[v] = 1;
@@ -384,47 +423,55 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
       }
     }
     if (wave > 0) {
-      double* dm = mm + (size_t)(wave - 1) * kDoubles * 64;
-      int32_t* de = me + (size_t)(wave - 1) * kInts * 64;
+      double* dm = record_m(wave);
+      int32_t* de = record_e(wave);
+      if constexpr (PROD) {
 #pragma unroll
-      for (int32_t d = 0; d < D0; ++d)
+        for (int32_t d = 0; d < D0; ++d)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          dm[(d * V + v) * 64 + lane] = pm[d][v];
-          de[(d * V + v) * 64 + lane] = pe[d][v];
-        }
+          for (int32_t v = 0; v < V; ++v) {
+            dm[(d * V + v) * 64 + lane] = pm[d][v];
+            de[(d * V + v) * 64 + lane] = pe[d][v];
+          }
+      }
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
-        dm[(D0 * V + v) * 64 + lane] = pz[v];
-        de[(D0 * V + v) * 64 + lane] = pze[v];
-        dm[(D0 * V + V + v) * 64 + lane] = zin_m[v];
-        de[(D0 * V + V + v) * 64 + lane] = zin_e[v];
+        dm[(kZ + v) * 64 + lane] = pz[v];
+        de[(kZ + v) * 64 + lane] = pze[v];
+        if constexpr (PROD) {
+          dm[(kZ + V + v) * 64 + lane] = zin_m[v];
+          de[(kZ + V + v) * 64 + lane] = zin_e[v];
+        }
       }
     }
     __syncthreads();
     if (wave > 0) return;
     for (int32_t j = 0; j < kWavesPerBlock - 1; ++j) {
-      const double* dm = mm + (size_t)j * kDoubles * 64;
-      const int32_t* de = me + (size_t)j * kInts * 64;
+      const double* dm = record_m(j + 1);
+      const int32_t* de = record_e(j + 1);
+      if constexpr (PROD) {
 #pragma unroll
-      for (int32_t d = 0; d < D0; ++d)
+        for (int32_t d = 0; d < D0; ++d)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) {
-          pm[d][v] *= dm[(d * V + v) * 64 + lane];
-          pe[d][v] += (short)de[(d * V + v) * 64 + lane];
-        }
+          for (int32_t v = 0; v < V; ++v) {
+            pm[d][v] *= dm[(d * V + v) * 64 + lane];
+            pe[d][v] += (short)de[(d * V + v) * 64 + lane];
+          }
+      }
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
-        pz[v] *= dm[(D0 * V + v) * 64 + lane];
-        pze[v] += de[(D0 * V + v) * 64 + lane];
-        if constexpr (STATE != kLoopChunk) {
-          zin_m[v] *= dm[(D0 * V + V + v) * 64 + lane];
-          zin_e[v] += de[(D0 * V + V + v) * 64 + lane];
+        pz[v] *= dm[(kZ + v) * 64 + lane];
+        pze[v] += de[(kZ + v) * 64 + lane];
+        if constexpr (PROD) {
+          zin_m[v] *= dm[(kZ + V + v) * 64 + lane];
+          zin_e[v] += de[(kZ + V + v) * 64 + lane];
         }
       }
     }
   }
+  const int64_t zat = (int64_t)(a.chunk_base + chunk) * a.npad + obs0;
   if constexpr (!LAST) {
+    // prod z of the next iteration: what the combine after the next one divides by
     double2 m;
     int2 e;
     int de = 0;
@@ -432,29 +479,36 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     e.x = pze[0] + de;
     m.y = frexp(pz[1], &de);
     e.y = pze[1] + de;
-    *reinterpret_cast<double2*>(a.zc_mant + (int64_t)chunk * a.npad + obs0) = m;
-    *reinterpret_cast<int2*>(a.zc_exp + (int64_t)chunk * a.npad + obs0) = e;
+    *reinterpret_cast<double2*>(a.zdiv_next_mant + zat) = m;
+    *reinterpret_cast<int2*>(a.zdiv_next_exp + zat) = e;
   }
-  // the chunk's partial product of the messages to the parent: prod q / prod z
-  double inv_z[V];
-#pragma unroll
-  for (int32_t v = 0; v < V; ++v) {
+  if constexpr (PROD) {
+    // prod z of this iteration: what the next combine divides by
+    double2 m;
+    int2 e;
     int de = 0;
-    inv_z[v] = 1.0 / frexp(zin_m[v], &de);
-    zin_e[v] += de;
+    m.x = frexp(zin_m[0], &de);
+    e.x = zin_e[0] + de;
+    m.y = frexp(zin_m[1], &de);
+    e.y = zin_e[1] + de;
+    *reinterpret_cast<double2*>(a.zdiv_mant + zat) = m;
+    *reinterpret_cast<int2*>(a.zdiv_exp + zat) = e;
   }
+  // ... and its numerator prod q, once per call
+  if constexpr (PROD) {
 #pragma unroll
-  for (int32_t s = 0; s < D0; ++s) {
-    int32_t ex[V];
+    for (int32_t s = 0; s < D0; ++s) {
+      int32_t ex[V];
 #pragma unroll
-    for (int32_t v = 0; v < V; ++v) {
-      int de = 0;
-      pm[s][v] = frexp(pm[s][v] * inv_z[v], &de);
-      ex[v] = (int32_t)pe[s][v] + de - zin_e[v];
+      for (int32_t v = 0; v < V; ++v) {
+        int de = 0;
+        pm[s][v] = frexp(pm[s][v], &de);
+        ex[v] = (int32_t)pe[s][v] + de;
+      }
+      const int64_t row = ((int64_t)(a.chunk_base + chunk) * D0 + s) * a.npad + obs0;
+      *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
+      *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(ex[0], ex[1]);
     }
-    const int64_t row = ((int64_t)(a.chunk_base + chunk) * D0 + s) * a.npad + obs0;
-    *reinterpret_cast<double2*>(a.part_mant + row) = make_double2(pm[s][0], pm[s][1]);
-    *reinterpret_cast<int2*>(a.part_exp + row) = make_int2(ex[0], ex[1]);
   }
 }
 

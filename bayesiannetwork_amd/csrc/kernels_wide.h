@@ -53,6 +53,15 @@ struct WideArgs {
   int32_t n_uncovered;
   double* part_mant;  // [chunks][S][npad]
   int32_t* part_exp;  // [chunks][S][npad]
+  // per-observation divisor of each chunk's partial product (mantissa in [0.5, 1), exponent), kept
+  // by the leaf-family kernels of a fused node; nullptr = the partial products are complete
+  const double* zdiv_mant;  // [chunks][npad]
+  const int32_t* zdiv_exp;  // [chunks][npad]
+  // the product of all chunk partials per state: prod_mode 1 = store it after forming it,
+  // 2 = read it instead of the partials (they have not changed since it was stored), 0 = neither
+  double* prod_mant;  // [S][npad]
+  int32_t* prod_exp;  // [S][npad]
+  int32_t prod_mode;
   double* scaled;     // [S][npad]   P'[s]
   int64_t npad;
   int64_t ntiles;
@@ -62,6 +71,34 @@ struct WideArgs {
   double fresh_mant;
   int32_t fresh_exp;
 };
+
+// 1 / prod_chunks zdiv for observation n, as a mantissa (0.5, 1] and an exponent
+__device__ __forceinline__ void divisor_product(const WideArgs& a, int64_t n, double& inv_m, int32_t& inv_e) {
+  double m = 1.0;
+  int32_t e = 0;
+  // mantissas lie in [0.5, 1): sixteen of them multiply without leaving double range
+  for (int32_t ch = 0; ch < a.chunks; ch += 16) {
+    double zm[16];
+    int32_t ze[16];
+#pragma unroll
+    for (int32_t u = 0; u < 16; ++u) {
+      const bool live = ch + u < a.chunks;
+      const int64_t at = (int64_t)(live ? ch + u : ch) * a.npad + n;
+      zm[u] = live ? a.zdiv_mant[at] : 1.0;
+      ze[u] = live ? a.zdiv_exp[at] : 0;
+    }
+#pragma unroll
+    for (int32_t u = 0; u < 16; ++u) {
+      m *= zm[u];
+      e += ze[u];
+    }
+    int de = 0;
+    m = frexp(m, &de);
+    e += de;
+  }
+  inv_m = 1.0 / m;
+  inv_e = -e;
+}
 
 template <int S>
 __device__ __forceinline__ void renorm(double (&m)[S][4], int32_t (&e)[S][4]) {
@@ -158,7 +195,15 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
   }
   // partial mantissas lie in [0.5, 1) (or are 0): a few dozen of them multiply without leaving
   // double range, so one renormalisation per group of four loads is plenty
-  for (int32_t ch = wave * 4; ch < (a.fresh ? 0 : a.chunks); ch += nw * 4) {
+  const bool stored = !a.fresh && a.prod_mode == 2;
+  if (stored && wave == 0) {
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      m[s] = a.prod_mant[(int64_t)s * a.npad + n];
+      e[s] = a.prod_exp[(int64_t)s * a.npad + n];
+    }
+  }
+  for (int32_t ch = wave * 4; ch < (a.fresh || stored ? 0 : a.chunks); ch += nw * 4) {
     double pm[4][S];
     int32_t pe[4][S];
 #pragma unroll
@@ -206,6 +251,23 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
         m[s] = frexp(m[s] * lds_m[(w * S + s) * 64 + lane], &de);
         e[s] += lds_e[(w * S + s) * 64 + lane] + de;
       }
+    }
+  }
+  if (!a.fresh && a.prod_mode == 1) {
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      a.prod_mant[(int64_t)s * a.npad + n] = m[s];
+      a.prod_exp[(int64_t)s * a.npad + n] = e[s];
+    }
+  }
+  if (!a.fresh && a.zdiv_mant) {
+    double inv_m;
+    int32_t inv_e;
+    divisor_product(a, n, inv_m, inv_e);
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      m[s] *= inv_m;
+      e[s] += inv_e;
     }
   }
   // inputs no partial covers
@@ -288,8 +350,13 @@ __global__ void __launch_bounds__(64 * S) wide_combine_states(T* __restrict__ ar
   double m = a.fresh ? a.fresh_mant : 1.0;
   int32_t e = a.fresh ? a.fresh_exp : 0;
   if (!a.fresh) {
+    const bool stored = a.prod_mode == 2;
+    if (stored) {
+      m = a.prod_mant[(int64_t)s * a.npad + n];
+      e = a.prod_exp[(int64_t)s * a.npad + n];
+    }
     // mantissas lie in [0.5, 1) or are 0: sixteen of them multiply without leaving double range
-    for (int32_t ch = 0; ch < a.chunks; ch += 16) {
+    for (int32_t ch = 0; ch < (stored ? 0 : a.chunks); ch += 16) {
       double pm[16];
       int32_t pe[16];
 #pragma unroll
@@ -311,6 +378,17 @@ __global__ void __launch_bounds__(64 * S) wide_combine_states(T* __restrict__ ar
       int de = 0;
       m = frexp(m, &de);
       e += de;
+    }
+    if (a.prod_mode == 1) {
+      a.prod_mant[(int64_t)s * a.npad + n] = m;
+      a.prod_exp[(int64_t)s * a.npad + n] = e;
+    }
+    if (a.zdiv_mant) {
+      double inv_m;
+      int32_t inv_e;
+      divisor_product(a, n, inv_m, inv_e);
+      m *= inv_m;
+      e += inv_e;
     }
   }
   // inputs no partial covers (their values are needed again for the outgoing messages)
@@ -371,6 +449,16 @@ __global__ void __launch_bounds__(64 * S) wide_combine_states(T* __restrict__ ar
         arena[dst + (t * S + s) * tile_of<T>::value + col] = (T)(lds_q[(u * S + s) * 64 + lane] * sum);
       }
     }
+  }
+}
+
+// divisors of the partial products := 1 (after the partial products were rebuilt from stored messages)
+template <typename E>
+__global__ void __launch_bounds__(256) wide_divisor_one(double* __restrict__ zdiv_mant, E* __restrict__ zdiv_exp,
+                                                       int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    zdiv_mant[i] = 0.5;
+    zdiv_exp[i] = 1;
   }
 }
 

@@ -4,5 +4,5 @@
 
 namespace bn {
 template int launch_leaf_family<float>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, float*, const float*, int32_t,
-                                     int32_t, int32_t, hipStream_t, bool, bool);
+                                     int32_t, int32_t, hipStream_t, bool, int32_t);
 }  // namespace bn

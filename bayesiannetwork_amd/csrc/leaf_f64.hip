@@ -4,5 +4,5 @@
 
 namespace bn {
 template int launch_leaf_family<double>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, double*, const double*, int32_t,
-                                     int32_t, int32_t, hipStream_t, bool, bool);
+                                     int32_t, int32_t, hipStream_t, bool, int32_t);
 }  // namespace bn
