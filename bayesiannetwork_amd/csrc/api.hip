@@ -1646,6 +1646,8 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
       bn::set_ingest_next(p, true, true, on_value, off_value);
     } else {
       bn::set_ingest_next(p, true);
+      // the plan is reset when the step ends: nothing would ever read its copy of the evidence
+      bn::set_evidence_in_caller(p, bn::caller_evidence_possible(p, num_iterations));
     }
   }
   if (int rc = settle_observations(p, s)) return rc;
@@ -1684,6 +1686,7 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
         return p.dtype == BN_F32 ? reset_messages_t<float>(p, on) : reset_messages_t<double>(p, on);
       });
   bn::set_ingest_next(p, false);
+  bn::set_evidence_in_caller(p, false);
   if (rc != BN_OK) return rc;
   if (from_graph)
     BN_HIP_CHECK(hipMemcpyAsync(new_cpts_dev, p.cpts, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice, s));

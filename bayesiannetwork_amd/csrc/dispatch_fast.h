@@ -109,6 +109,23 @@ inline bool ingest_possible(const Plan& p) {
   return st && st->ingest_ok;
 }
 
+// Can every launch of an EM step read float evidence from the caller's arrays?  The step must ingest
+// (ingest_possible), leave out the loop launch before the reduce launch (three iterations at least),
+// and every fused group must have the reduce kernel that reads those arrays (float plans, two-state
+// leaves, four observations per lane).
+inline bool caller_evidence_possible(const Plan& p, int32_t num_iterations) {
+  FastState* st = fast_state(p);
+  if (!st || !st->ingest_ok || p.dtype != 0 || p.tile != 256 || num_iterations < 3) return false;
+  if (env_copy_evidence() || env_no_recompute() || env_reduce_v2()) return false;
+  for (const auto& kv : st->fused)
+    if (kv.second.wide_index2 >= 0 || p.fgroups[kv.first].dims[1] != 2) return false;
+  return !st->fused.empty();
+}
+
+inline void set_evidence_in_caller(Plan& p, bool on) {
+  if (FastState* st = fast_state(p)) st->evidence_in_caller = on;
+}
+
 inline void set_ingest_next(Plan& p, bool on, bool from_states = false, double on_value = 1.0, double off_value = 0.0) {
   if (FastState* st = fast_state(p)) {
     st->ingest_next = on;
@@ -874,6 +891,7 @@ inline void append_state_signature(const Plan& p, std::string& key) {
   if (!st) return;
   auto put = [&](const auto& v) { key.append(reinterpret_cast<const char*>(&v), sizeof v); };
   put(st->ingest_next);
+  put(st->evidence_in_caller);
   put(st->ingest_states);
   put(st->ingest_on);
   put(st->ingest_off);

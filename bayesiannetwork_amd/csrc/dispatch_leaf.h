@@ -36,8 +36,8 @@ struct LeafLoopKernel {
 
 template <typename T, int D0, int OUT, int STATE>
 inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s, bool split) {
-  constexpr bool kFromCaller = STATE == kLoopIngest;
-  constexpr bool kLight = STATE == kLoopChunk;
+  constexpr bool kFromCaller = loop_reads_caller(STATE);
+  constexpr bool kLight = loop_is_light(STATE);
   // blocks that share a chunk: instantiated for two-state leaves
   if (split)
     return s == 2 ? LeafLoopKernel<T>{leaf_loop_p1<T, D0, 2, OUT, STATE, true>,
@@ -46,7 +46,7 @@ inline LeafLoopKernel<T> leaf_loop_for_s(int32_t s, bool split) {
   switch (s) {
 #define X(SV)                                                                                       \
   case SV:                                                                                          \
-    if constexpr (SV == 2 || (STATE != kLoopIngest && STATE != kLoopIngestStates))                  \
+    if constexpr (SV == 2 || (!loop_reads_caller(STATE) && STATE != kLoopIngestStates))             \
       return {leaf_loop_p1<T, D0, SV, OUT, STATE>,                                                  \
               (size_t)kWavesPerBlock * LeafRing<T, SV, kFromCaller, kLight>::kWaveBytes};           \
     break;
@@ -123,16 +123,20 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     loop_out = next_is_last ? kLoopLast : kLoopLight;
     if (state == kLeafRecompute) return -1;  // no loop launch continues from there
     int32_t from = fresh ? kLoopFresh : (first_iteration ? kLoopFromArrays : kLoopChunk);
+    const bool in_caller = fast_state(p)->evidence_in_caller;
     if (ingest_wanted) {
       if (loop_out != kLoopLight) return -1;  // callers ask for ingestion only with a loop launch to spare
-      from = fast_state(p)->ingest_states ? kLoopIngestStates : kLoopIngest;
+      from = fast_state(p)->ingest_states ? kLoopIngestStates : (in_caller ? kLoopIngestKeep : kLoopIngest);
+    } else if (in_caller) {
+      if (from != kLoopChunk || loop_out != kLoopLight) return -1;  // (the launch before the reduce launch is left out)
+      from = kLoopChunkCaller;
     }
-    if (from == kLoopChunk && fam.z_form != kZPerChunk) return -1;
+    if (loop_is_light(from) && fam.z_form != kZPerChunk) return -1;
     // A launch that carries no per-state product needs half the registers: the waves of a block then
     // share a chunk at every batch size (four times the waves, each a quarter as long, six to
     // seven of them resident per SIMD instead of four).
-    light = from == kLoopChunk;
-    split = fam.split > 1 || (from == kLoopChunk && g.dims[1] == 2 && !env_no_light_split());
+    light = loop_is_light(from);
+    split = fam.split > 1 || (light && g.dims[1] == 2 && !env_no_light_split());
     LeafLoopKernel<T> k;
     switch (loop_out * 8 + from) {
 #define X(OUT, FROM)                                                      \
@@ -140,7 +144,8 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1], split); \
     break;
       X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
-      X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates)
+      X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates) X(kLoopLight, kLoopIngestKeep)
+      X(kLoopLight, kLoopChunkCaller)
       X(kLoopLast, kLoopChunk) X(kLoopLast, kLoopFresh) X(kLoopLast, kLoopFromArrays)
 #undef X
     }
@@ -184,8 +189,13 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
         case kLeafSteady: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafSteady>(g.dims[0]); break;
         case kLeafFresh: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFresh>(g.dims[0]); break;
         case kLeafFromArrays: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafFromArrays>(g.dims[0]); break;
-        case kLeafRecompute: fn4 = leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafRecompute>(g.dims[0]); break;
+        case kLeafRecompute:
+          fn4 = fast_state(p)->evidence_in_caller
+                    ? leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafRecompute + kLeafCaller>(g.dims[0])
+                    : leaf_family_lookup_pairs4<T, kLeafReduce + 3 * kLeafRecompute>(g.dims[0]);
+          break;
       }
+      if (fast_state(p)->evidence_in_caller && state != kLeafRecompute) return -1;
       if (fn4) {
         // 140 VGPRs, three waves per SIMD: one round of resident waves (3 x 1024) per launch
         int64_t want = std::max<int64_t>(1, 3072 / p.ntiles);

@@ -132,6 +132,9 @@ struct FastState {
   bool ingest_states = false;  // ... from uint8 states (bn_enter_evidence_states' format) instead of float arrays
   bool ingest_all_observed = false;  // every leaf of every ingesting group is observed (the uint8 route needs it)
   double ingest_on = 1.0, ingest_off = 0.0;
+  // An EM step (bn_em_step) on such a plan: no launch of the call copies the evidence, they all read
+  // the caller's arrays (the plan is reset when the step ends, the copy would never be read again).
+  bool evidence_in_caller = false;
 };
 
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).
@@ -171,6 +174,11 @@ inline bool env_no_light_split() {
 // BN_NO_RECOMPUTE=1  the loop launch before a reduce launch always runs (and stores the leaves' normalisers)
 inline bool env_no_recompute() {
   static const bool v = getenv("BN_NO_RECOMPUTE") != nullptr;
+  return v;
+}
+// BN_COPY_EVIDENCE=1  an EM step copies the evidence into the plan like bn_em_statistics_from does
+inline bool env_copy_evidence() {
+  static const bool v = getenv("BN_COPY_EVIDENCE") != nullptr;
   return v;
 }
 inline bool env_reduce_v2() {

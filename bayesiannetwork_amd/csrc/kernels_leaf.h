@@ -72,6 +72,7 @@ constexpr int32_t kLeafLoop = 0, kLeafFull = 1, kLeafReduce = 2;
 //                    iteration (exactly what the loop launch of that iteration would have stored),
 //                    so that launch does not have to run at all.  P'prev is kept in LDS, per lane.
 constexpr int32_t kLeafSteady = 0, kLeafFresh = 1, kLeafFromArrays = 2, kLeafRecompute = 3;
+constexpr int32_t kLeafCaller = 12;  // added to MODE: evidence from the caller's arrays (leaf_state)
 // dynamic LDS of a kLeafRecompute launch
 template <typename T, int D0, int V>
 constexpr size_t leaf_recompute_lds_bytes() {
@@ -107,7 +108,8 @@ struct WaveSums {
     const int32_t e = f + ((q >> 1) & 1) * H2;  // index after the first step
     return e < H1 ? e + (q & 1) * H1 : E;
   }
-  __device__ __forceinline__ void reduce(const T (&p)[E], int32_t lane) {
+  // the two steps inside the quads: afterwards out[f] is the quad's sum of this lane's entries
+  __device__ __forceinline__ void scatter(const T (&p)[E], int32_t lane) {
     const bool odd = lane & 1, upper = lane & 2;
     T y[H1];
 #pragma unroll
@@ -118,13 +120,25 @@ struct WaveSums {
 #pragma unroll
     for (int32_t f = 0; f < H2; ++f) {
       const T a = y[f], b = f + H2 < H1 ? y[f + H2] : 0.f;
-      T w = (upper ? b : a) + dpp_move<0x4E>(upper ? a : b);  // quad_perm [2,3,0,1]
-      w += dpp_move<0x124>(w);                                     // row_ror:4
-      w += dpp_move<0x128>(w);                                     // row_ror:8
+      out[f] = (upper ? b : a) + dpp_move<0x4E>(upper ? a : b);  // quad_perm [2,3,0,1]
+    }
+  }
+  // the sum over the sixteen quads: a chain of dependent cross-lane steps with little to overlap
+  // among themselves, so callers run it next to independent arithmetic (the next family's)
+  __device__ __forceinline__ void finish() {
+#pragma unroll
+    for (int32_t f = 0; f < H2; ++f) {
+      T w = out[f];
+      w += dpp_move<0x124>(w);  // row_ror:4
+      w += dpp_move<0x128>(w);  // row_ror:8
       w += __shfl_xor(w, 16, 64);
       w += __shfl_xor(w, 32, 64);
       out[f] = w;
     }
+  }
+  __device__ __forceinline__ void reduce(const T (&p)[E], int32_t lane) {
+    scatter(p, lane);
+    finish();
   }
 };
 
@@ -183,7 +197,7 @@ struct LeafState {
   fv<T, V> z;  // the leaf's normaliser for this iteration: sum_s ev[s] * (previous message from the factor)[s]
 };
 
-template <typename T>
+template <typename T, bool CALLER = false>
 __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T* __restrict__ cpts,
                                                  const LeafFamilyArgs<T>& a, int32_t k) {
   LeafPtrs<T> p;
@@ -193,7 +207,7 @@ __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T*
   p.v2f_own = arena + a.f_in[2 * k + 1];
   p.c = arena + a.c_off[k];
   p.z = a.z_state + (int64_t)k * a.npad;
-  p.obs = arena + a.obs_off[k];
+  p.obs = CALLER ? static_cast<const T*>(a.src[k]) : arena + a.obs_off[k];
   p.cpt = cpts + a.cpt_off[k];
   return p;
 }
@@ -214,12 +228,36 @@ __device__ __forceinline__ fv<T, V> recipv(const fv<T, V>& x) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, splat<T, V>(1.f)), r, r);
 }
 
-template <typename T, int S, int V, int STATE>
+// CALLER: the evidence is read from the caller's [N][S] array of the leaf (p.obs points there): a
+// lane's observations are one contiguous run of V * S values, fetched in 16-byte pieces that are
+// clamped to the end of the array (padding observations then read real ones; they are masked out of
+// every sum).  Two-state leaves of float plans with four observations per lane.
+template <typename T, int S, int V, int STATE, bool CALLER = false>
 __device__ __forceinline__ LeafState<T, S, V> leaf_state(const LeafPtrs<T>& p, const LeafFamilyArgs<T>& a, int64_t t,
                                                       int32_t col) {
   LeafState<T, S, V> st;
+  if constexpr (CALLER) {
+    static_assert(S == 2 && V == 4 && sizeof(T) == 4, "caller-side evidence: two-state float leaves, four observations per lane");
+    // (32-bit byte offsets: an evidence array of two-state float rows stays below 4 GB up to 2^29 observations)
+    const uint32_t last_piece = (uint32_t)(a.N * (int64_t)(S * sizeof(T)) - 16);
+    uint32_t at0 = (uint32_t)((t * tile_of<T>::value + col) * (int64_t)(S * sizeof(T))), at1 = at0 + 16;
+    at0 = at0 < last_piece ? at0 : last_piece;
+    at1 = at1 < last_piece ? at1 : last_piece;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(p.obs);
+    const fv<T, 4> x = *reinterpret_cast<const fv<T, 4>*>(base + at0);
+    const fv<T, 4> y = *reinterpret_cast<const fv<T, 4>*>(base + at1);
+    st.ev[0][0] = x[0];
+    st.ev[1][0] = x[1];
+    st.ev[0][1] = x[2];
+    st.ev[1][1] = x[3];
+    st.ev[0][2] = y[0];
+    st.ev[1][2] = y[1];
+    st.ev[0][3] = y[2];
+    st.ev[1][3] = y[3];
+  } else {
 #pragma unroll
-  for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
+    for (int32_t j = 0; j < S; ++j) st.ev[j] = loadv<T, V>(p.obs, t * S + j, col);
+  }
   if constexpr (STATE == kLeafRecompute) {
     st.z = splat<T, V>((T)1);  // formed in the family loop
   } else if constexpr (STATE != kLeafSteady) {
@@ -247,7 +285,10 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
   constexpr bool FULL = MODE % 3 == kLeafFull;
   constexpr bool REDUCE = MODE % 3 == kLeafReduce;
   static_assert(FULL || REDUCE, "loop launches of one-parent families run on leaf_loop_p1");
-  constexpr int32_t STATE = MODE / 3;
+  // MODE = mode + 3 * state (+ kLeafCaller when the evidence is read from the caller's arrays)
+  constexpr bool CALLER = MODE >= kLeafCaller;
+  constexpr int32_t STATE = (MODE % kLeafCaller) / 3;
+  static_assert(!CALLER || REDUCE, "only a reduce launch reads the caller's arrays: it stores nothing that would outlive them");
   constexpr int32_t kParts = tile_of<T>::value / (64 * V);
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -324,12 +365,19 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     pze[v] = 0;
   }
 
-  LeafPtrs<T> ptr = leaf_ptrs<T>(arena, cpts, a, first);
-  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE>(ptr, a, t, col);
+  // reduce mode: the count sums of the previous family after their steps inside the quads (not when
+  // the evidence comes from the caller's arrays: the registers this costs would take the launch from
+  // three waves per SIMD to two)
+  constexpr bool kHoldSums = !CALLER;
+  WaveSums<T, D0 * S> held;
+  T* held_dst = nullptr;
+
+  LeafPtrs<T> ptr = leaf_ptrs<T, CALLER>(arena, cpts, a, first);
+  LeafState<T, S, V> cur = leaf_state<T, S, V, STATE, CALLER>(ptr, a, t, col);
   for (int32_t k = first; k < last; ++k) {
     const int32_t kn = k + 1 < last ? k + 1 : k;
-    const LeafPtrs<T> ptr_next = leaf_ptrs<T>(arena, cpts, a, kn);
-    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE>(ptr_next, a, t, col);
+    const LeafPtrs<T> ptr_next = leaf_ptrs<T, CALLER>(arena, cpts, a, kn);
+    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE, CALLER>(ptr_next, a, t, col);
     const T* cpt = ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the
@@ -349,8 +397,9 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       // the same operations, in the same order, as the loop launch's z' = sum(P') / sum(P' / q)
       fv<T, V> sum_r = splat<T, V>(0.f);
       // read again for every family (held in registers over the loop, P'prev would cost a wave per SIMD)
-      const fv<T, V>* prev_here = prev_pf;
-      asm volatile("" : "+v"(prev_here));
+      uint32_t prev_at = (uint32_t)(((size_t)wave * D0 * 64 + lane) * sizeof(fv<T, V>));
+      asm volatile("" : "+v"(prev_at));
+      const fv<T, V>* prev_here = reinterpret_cast<const fv<T, V>*>(recompute_raw + prev_at);
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
         const fv<T, V> rq = rcpv<T, V>(q[i]);
@@ -411,14 +460,32 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
             for (int32_t v = 1; v < V; ++v) x = fma_t(r[i][v], o[j][v], x);
             per_lane[i * S + j] = x;
           }
+        // the sums over the wave of the family before this one are finished here, next to this
+        // family's arithmetic, and this family's wait for the next turn
         WaveSums<T, D0 * S> sums;
-        sums.reduce(per_lane, lane);
-        if (lane < 4) {
+        sums.scatter(per_lane, lane);
+        if constexpr (!kHoldSums) {
+          sums.finish();
+          if (lane < 4) {
 #pragma unroll
-          for (int32_t f = 0; f < WaveSums<T, D0 * S>::H2; ++f) {
-            const int32_t e = WaveSums<T, D0 * S>::entry(lane, f);
-            if (e < D0 * S) dst[(int64_t)e * a.slots] = sums.out[f];
+            for (int32_t f = 0; f < WaveSums<T, D0 * S>::H2; ++f) {
+              const int32_t e = WaveSums<T, D0 * S>::entry(lane, f);
+              if (e < D0 * S) dst[(int64_t)e * a.slots] = sums.out[f];
+            }
           }
+        } else if (held_dst) {
+          held.finish();
+          if (lane < 4) {
+#pragma unroll
+            for (int32_t f = 0; f < WaveSums<T, D0 * S>::H2; ++f) {
+              const int32_t e = WaveSums<T, D0 * S>::entry(lane, f);
+              if (e < D0 * S) held_dst[(int64_t)e * a.slots] = held.out[f];
+            }
+          }
+        }
+        if constexpr (kHoldSums) {
+          held = sums;
+          held_dst = dst;
         }
       }
       ptr = ptr_next;
@@ -484,6 +551,16 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     cur = nxt;
   }
   if constexpr (REDUCE) {
+    if (held_dst) {
+      held.finish();
+      if (lane < 4) {
+#pragma unroll
+        for (int32_t f = 0; f < WaveSums<T, D0 * S>::H2; ++f) {
+          const int32_t e = WaveSums<T, D0 * S>::entry(lane, f);
+          if (e < D0 * S) held_dst[(int64_t)e * a.slots] = held.out[f];
+        }
+      }
+    }
     double* dst = a.ll_part + (int64_t)chunk * a.npad + t * tile_of<T>::value + col;
 #pragma unroll
     for (int32_t v = 0; v < V; ++v) {

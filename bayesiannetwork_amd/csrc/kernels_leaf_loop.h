@@ -34,7 +34,15 @@ constexpr int32_t kLoopLight = 0, kLoopLast = 1;
 //   kLoopIngest        as kLoopFresh, evidence read from the caller's [N][2] arrays and copied into
 //                      the arena on the way (two-state leaves)
 //   kLoopIngestStates  as kLoopIngest, from one uint8 state per observation
-constexpr int32_t kLoopChunk = 0, kLoopFresh = 1, kLoopFromArrays = 2, kLoopIngest = 3, kLoopIngestStates = 4;
+//   kLoopIngestKeep    as kLoopIngest without the copy: every launch of the call reads the caller's
+//                      arrays (an EM step, after which the plan's copy would be void anyway)
+//   kLoopChunkCaller   as kLoopChunk, evidence read from the caller's arrays
+constexpr int32_t kLoopChunk = 0, kLoopFresh = 1, kLoopFromArrays = 2, kLoopIngest = 3, kLoopIngestStates = 4,
+                  kLoopIngestKeep = 5, kLoopChunkCaller = 6;
+constexpr bool loop_reads_caller(int32_t state) {
+  return state == kLoopIngest || state == kLoopIngestKeep || state == kLoopChunkCaller;
+}
+constexpr bool loop_is_light(int32_t state) { return state == kLoopChunk || state == kLoopChunkCaller; }
 
 typedef const __attribute__((address_space(4))) int64_t* const_table_ptr;  // read through the scalar cache
 
@@ -98,17 +106,19 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
                                                    LeafFamilyArgs<T> a) {
   constexpr int32_t V = 2;
   constexpr bool LAST = OUT == kLoopLast;
-  constexpr bool INGEST = STATE == kLoopIngest, INGEST_STATES = STATE == kLoopIngestStates;
-  constexpr bool FRESH = STATE == kLoopFresh || INGEST || INGEST_STATES;
+  // INGEST: the evidence comes from the caller's [N][S] arrays; COPY: ... and is written to the arena
+  constexpr bool INGEST = loop_reads_caller(STATE), INGEST_STATES = STATE == kLoopIngestStates;
+  constexpr bool COPY = STATE == kLoopIngest || INGEST_STATES;
+  constexpr bool FRESH = STATE == kLoopFresh || STATE == kLoopIngest || STATE == kLoopIngestKeep || INGEST_STATES;
   // the first loop launch of a call forms prod q per state; the others reuse what it wrote
-  constexpr bool PROD = STATE != kLoopChunk;
+  constexpr bool PROD = !loop_is_light(STATE);
   static_assert(!(INGEST || INGEST_STATES) || S == 2, "evidence is taken from the caller's arrays for two-state leaves only");
-  using Ring = LeafRing<T, S, INGEST, STATE == kLoopChunk>;
+  using Ring = LeafRing<T, S, INGEST, !PROD>;
   constexpr int32_t R = Ring::kDepth, ND = Ring::kDmas;
   // vector-memory operations issued per family besides the DMAs (they sit between the DMAs in the
   // queue, so the counted waits allow for them): the z store of kLoopLast, the arena copy of the
   // evidence when ingesting
-  constexpr int32_t kOther = (LAST ? 1 : 0) + ((INGEST || INGEST_STATES) ? S : 0);
+  constexpr int32_t kOther = (LAST ? 1 : 0) + (COPY ? S : 0);
   constexpr int32_t kAhead = (R - 1) * (ND + kOther);
   constexpr int32_t kParts = tile_of<T>::value / (64 * V);
   constexpr int32_t E = D0 * S;
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
       }
       read_slot(in % R, nxt_ev);
     }
-    if constexpr (INGEST || INGEST_STATES) {
+    if constexpr (COPY) {
       // the arena copy of the evidence (an unobserved leaf rewrites the shared all-ones array)
       T* dst = arena + obs_tab[k];
 #pragma unroll
@@ -314,7 +324,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
       for (int32_t j = 1; j < S; ++j) q[d] = __builtin_elementwise_fma(splat<T, V>(cpt_cur[d * S + j]), cur_ev[j], q[d]);
     }
     // this iteration's z of the leaf where it is not part of the state that was read
-    if constexpr (STATE != kLoopChunk) {
+    if constexpr (PROD) {
       fv<T, V> own[S];
 #pragma unroll
       for (int32_t j = 0; j < S; ++j)
@@ -327,11 +337,11 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     // to the parent); in the steady state r = P' / q and z' = sum(P') / sum(r)
     fv<T, V> zn;
 #ifdef BN_X_NOCOMPUTE
-    if constexpr (STATE == kLoopChunk) {
+    if constexpr (!PROD) {
       zn = cur_ev[0] + cur_ev[1];
     } else
 #endif
-    if constexpr (STATE == kLoopChunk) {
+    if constexpr (!PROD) {
       fv<T, V> sum_r = splat<T, V>(0.f);
 #pragma unroll
       for (int32_t d = 0; d < D0; ++d) sum_r = __builtin_elementwise_fma(pf[d], rcpv<T, V>(q[d]), sum_r);
@@ -370,7 +380,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
 #pragma unroll
       for (int32_t v = 0; v < V; ++v) {
         if constexpr (!LAST) pze[v] += frexp_in_place(pz[v]);
-        if constexpr (STATE != kLoopChunk) zin_e[v] += frexp_in_place(zin_m[v]);
+        if constexpr (PROD) zin_e[v] += frexp_in_place(zin_m[v]);
       }
     }
     if constexpr (INGEST_STATES) {
