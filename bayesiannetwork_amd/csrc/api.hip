@@ -651,8 +651,11 @@ int upload_evidence_table(bn::Plan& p, const void* const* evidence_dev, hipStrea
 
 // For an ingesting first iteration: per fused family group, the evidence source of every leaf in
 // the group's own order (the leaf's all-ones stand-in array when it is not observed).
+// strided_ok: the kernels that will read the sources take a base address and a distance instead of
+// the table when the sources lie at equal distances (the leaf-family launches of a statistics call
+// that is not captured into a graph: a graph would keep the base address of the call it was made from)
 int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStream_t s,
-                          const uint8_t* states_dev = nullptr) {
+                          const uint8_t* states_dev = nullptr, bool strided_ok = false) {
   bn::FastState* st = bn::fast_state(p);
   for (auto& kv : st->fused) {
     bn::FusedFamily& fam = kv.second;
@@ -665,6 +668,19 @@ int upload_family_sources(bn::Plan& p, const void* const* evidence_dev, hipStrea
         src[k] = states_dev + (int64_t)fam.ev_index[k] * p.N;
       else
         src[k] = fam.ev_index[k] >= 0 ? evidence_dev[fam.ev_index[k]] : ones;
+    }
+    fam.src_base = nullptr;
+    fam.src_stride = 0;
+    if (strided_ok && src.size() >= 2) {
+      const int64_t stride = static_cast<const char*>(src[1]) - static_cast<const char*>(src[0]);
+      bool even = stride != 0;
+      for (size_t k = 2; k < src.size() && even; ++k)
+        even = static_cast<const char*>(src[k]) - static_cast<const char*>(src[k - 1]) == stride;
+      if (even) {
+        fam.src_base = static_cast<const unsigned char*>(src[0]);
+        fam.src_stride = stride;
+        continue;  // no table needed
+      }
     }
     if (src == fam.src_on_device) continue;
     for (size_t first = 0; first < src.size(); first += bn::kAddressBatch) {
@@ -1640,7 +1656,8 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
                               : bn_enter_evidence(plan, evidence_dev, stream);
     if (rc != BN_OK) return rc;
   } else {
-    if (int rc = upload_family_sources(p, states_dev ? nullptr : evidence_dev, s, states_dev)) return rc;
+    const bool graphs_possible = step_graphs_enabled() && plan->graphs_wanted && !plan->graphs_off;
+    if (int rc = upload_family_sources(p, states_dev ? nullptr : evidence_dev, s, states_dev, !graphs_possible)) return rc;
     p.obs_pending = false;  // the first factor pass writes every observation array
     if (states_dev) {
       bn::set_ingest_next(p, true, true, on_value, off_value);

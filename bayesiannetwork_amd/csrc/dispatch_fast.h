@@ -112,13 +112,14 @@ inline bool ingest_possible(const Plan& p) {
 // Can every launch of an EM step read float evidence from the caller's arrays?  The step must ingest
 // (ingest_possible), leave out the loop launch before the reduce launch (three iterations at least),
 // and every fused group must have the reduce kernel that reads those arrays (float plans, two-state
-// leaves, four observations per lane).
+// leaves, four observations per lane; the arrays of a group's leaves at equal distances, as
+// upload_family_sources found them).
 inline bool caller_evidence_possible(const Plan& p, int32_t num_iterations) {
   FastState* st = fast_state(p);
   if (!st || !st->ingest_ok || p.dtype != 0 || p.tile != 256 || num_iterations < 3) return false;
   if (env_copy_evidence() || env_no_recompute() || env_reduce_v2()) return false;
   for (const auto& kv : st->fused)
-    if (kv.second.wide_index2 >= 0 || p.fgroups[kv.first].dims[1] != 2) return false;
+    if (kv.second.wide_index2 >= 0 || p.fgroups[kv.first].dims[1] != 2 || kv.second.src_stride == 0) return false;
   return !st->fused.empty();
 }
 
@@ -649,7 +650,10 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
       if (!launch_ok()) return false;
     }
   }
-  if (!fresh && a.prod_mode != 2 && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
+  // (large batches that also store the product over the chunks: measured 22 against 27 us at 60 000
+  // observations on the kernel with one observation per lane and a wave per four chunks)
+  const bool states_kernel = a.prod_mode == 1 ? p.ntiles < 64 : a.prod_mode != 2;
+  if (!fresh && states_kernel && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
     // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
     const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
     if (lds > 48 * 1024 &&
@@ -909,6 +913,8 @@ inline void append_state_signature(const Plan& p, std::string& key) {
     put(fam.pending_first);
     put(fam.em_ready);
     put(fam.z_form);
+    put(fam.src_base);
+    put(fam.src_stride);
     put(fam.ll_rows);
     put(fam.slots_used);
   }

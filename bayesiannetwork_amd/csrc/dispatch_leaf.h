@@ -238,6 +238,8 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   a.scaled2 = w2 ? w2->scaled : nullptr;
   a.m_state = static_cast<T*>(fam.m_state);
   a.src = fam.d_src;
+  a.src_base = fam.src_base;
+  a.src_stride = fam.src_stride;
   a.on_value = (T)fast_state(p)->ingest_on;
   a.off_value = (T)fast_state(p)->ingest_off;
   a.split = split ? kWavesPerBlock : 1;

@@ -64,6 +64,9 @@ struct FusedFamily {
   std::vector<int32_t> ev_index;   // [K] position of each leaf in the evidence order, -1 = not observed
   const void** d_src = nullptr;    // [K] evidence source of each leaf for an ingesting launch
   std::vector<const void*> src_on_device;  // what d_src holds
+  // the sources lie at equal distances: leaf k's is src_base + k * src_stride (0 = d_src is used)
+  const unsigned char* src_base = nullptr;
+  int64_t src_stride = 0;
   void* z_state = nullptr;      // [K][npad] loop-state normalisers (plan's element type)
   // where the leaves' normalisers of the coming iteration are: kZPerFamily (z_state, written by a
   // loop launch that a full launch follows), kZPerChunk (only their chunk products, in the parent's

@@ -46,6 +46,11 @@ struct LeafFamilyArgs {
   // ingesting loop launches only: per family, the caller's evidence array ([N][2], row-major) of its
   // leaf, or the leaf's stand-in observation array in the arena (all ones) when it is not observed
   const void* const* src;
+  // ... or, when those arrays lie at equal distances (slices of one buffer, what stacking the
+  // evidence and unbinding it gives), leaf k's array is src_base + k * src_stride bytes and no table
+  // is read (src_stride = 0: use the table)
+  const unsigned char* src_base;
+  int64_t src_stride;
   T on_value, off_value;  // evidence given as states: what an observed / any other state's row receives
   // leaf_loop_p1 only: 1, or kWavesPerBlock when the waves of a block share one (chunk, tile, part)
   // work item, each taking a quarter of the chunk's families (small batches: as many waves as
@@ -207,7 +212,12 @@ __device__ __forceinline__ LeafPtrs<T> leaf_ptrs(T* __restrict__ arena, const T*
   p.v2f_own = arena + a.f_in[2 * k + 1];
   p.c = arena + a.c_off[k];
   p.z = a.z_state + (int64_t)k * a.npad;
-  p.obs = CALLER ? static_cast<const T*>(a.src[k]) : arena + a.obs_off[k];
+  if constexpr (CALLER) {
+    // (a launch that reads the caller's arrays here requires them at equal distances: no table)
+    p.obs = reinterpret_cast<const T*>(a.src_base + (int64_t)k * a.src_stride);
+  } else {
+    p.obs = arena + a.obs_off[k];
+  }
   p.cpt = cpts + a.cpt_off[k];
   return p;
 }
@@ -365,19 +375,33 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
     pze[v] = 0;
   }
 
-  // reduce mode: the count sums of the previous family after their steps inside the quads (not when
-  // the evidence comes from the caller's arrays: the registers this costs would take the launch from
-  // three waves per SIMD to two)
-  constexpr bool kHoldSums = !CALLER;
+  // reduce mode: the count sums of the previous family after their steps inside the quads
+  constexpr bool kHoldSums = true;
   WaveSums<T, D0 * S> held;
   T* held_dst = nullptr;
 
+  // kDeep: the loop state is requested two families ahead instead of one (where the registers allow:
+  // the launch that reads the caller's arrays, which keeps no addresses per family)
+  constexpr bool kDeep = CALLER;
   LeafPtrs<T> ptr = leaf_ptrs<T, CALLER>(arena, cpts, a, first);
   LeafState<T, S, V> cur = leaf_state<T, S, V, STATE, CALLER>(ptr, a, t, col);
+  LeafPtrs<T> ptr_mid = ptr;
+  LeafState<T, S, V> mid = cur;
+  if constexpr (kDeep) {
+    ptr_mid = leaf_ptrs<T, CALLER>(arena, cpts, a, first + 1 < last ? first + 1 : first);
+    mid = leaf_state<T, S, V, STATE, CALLER>(ptr_mid, a, t, col);
+  }
   for (int32_t k = first; k < last; ++k) {
-    const int32_t kn = k + 1 < last ? k + 1 : k;
-    const LeafPtrs<T> ptr_next = leaf_ptrs<T, CALLER>(arena, cpts, a, kn);
-    const LeafState<T, S, V> nxt = leaf_state<T, S, V, STATE, CALLER>(ptr_next, a, t, col);
+    const int32_t ahead = kDeep ? 2 : 1;
+    const int32_t kn = k + ahead < last ? k + ahead : last - 1;
+    const LeafPtrs<T> ptr_far = leaf_ptrs<T, CALLER>(arena, cpts, a, kn);
+    const LeafState<T, S, V> far = leaf_state<T, S, V, STATE, CALLER>(ptr_far, a, t, col);
+    const LeafPtrs<T> ptr_next = kDeep ? ptr_mid : ptr_far;
+    const LeafState<T, S, V> nxt = kDeep ? mid : far;
+    if constexpr (kDeep) {
+      ptr_mid = ptr_far;
+      mid = far;
+    }
     const T* cpt = ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the

@@ -86,13 +86,8 @@ struct LeafRing {
   static constexpr int32_t kFamilyBytes = S * kRowBytes;                    // the same bytes in the caller's [N][S] layout
   static constexpr int32_t kDmas = (kFamilyBytes + 1023) / 1024;            // DMA instructions per family
   static constexpr int32_t kSlotBytes = kDmas * 1024;
-#ifdef BN_X_DEPTH
-  static constexpr int32_t kBudget = LIGHT ? BN_X_DEPTH * 1024 : 8192;
-  static constexpr int32_t kMaxDepth = LIGHT ? BN_X_DEPTH : 8;
-#else
   static constexpr int32_t kBudget = LIGHT ? 4096 : 8192;
   static constexpr int32_t kMaxDepth = LIGHT ? 4 : 8;
-#endif
   static constexpr int32_t kDepth =
       kBudget / kSlotBytes >= kMaxDepth ? kMaxDepth : (kBudget / kSlotBytes >= 2 ? kBudget / kSlotBytes : 2);
   static constexpr int32_t kWaveBytes = kDepth * kSlotBytes;
@@ -153,6 +148,10 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   const_table_ptr obs_tab = (const_table_ptr)a.obs_off;
   const_table_ptr cpt_tab = (const_table_ptr)a.cpt_off;
   const_table_ptr src_tab = (const_table_ptr)a.src;
+  // the caller's array of leaf k, as an address held in 64 bits
+  auto caller_source = [&](int32_t k) -> int64_t {
+    return a.src_stride ? (int64_t)(uintptr_t)a.src_base + (int64_t)k * a.src_stride : src_tab[k];
+  };
 
   // Byte offset, from the start of a family's evidence, of the 16 bytes this lane fetches in each
   // of the family's DMA instructions.  Arena layout: [tile][state][observation]; the wave's piece of
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   const uint32_t ring = (uint32_t)(uintptr_t)ring_raw + (uint32_t)wave * Ring::kWaveBytes;
   const unsigned char* my_ring = ring_raw + wave * Ring::kWaveBytes;
   auto family_source = [&](int32_t k) -> const void* {
-    if constexpr (INGEST) return reinterpret_cast<const void*>(src_tab[k]);
+    if constexpr (INGEST) return reinterpret_cast<const void*>(caller_source(k));
     return arena + obs_tab[k];
   };
   auto request = [&](const void* source, int32_t slot) {
@@ -203,7 +202,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   auto states_pair = [&](int32_t k) -> uint32_t {
     const bool tail = obs0 + 1 >= a.N;
     const int64_t at = tail ? a.N - 2 : obs0;
-    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(src_tab[k]) + at);
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(caller_source(k)) + at);
   };
   auto expand_states = [&](uint32_t pair, fv<T, V>* ev) {
     const uint32_t s0 = pair & 0xffu, s1 = pair >> 8;
@@ -258,7 +257,7 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
   int64_t ahead_off = 0;
   if constexpr (!INGEST_STATES) {
     const int32_t ka = first + R < last ? first + R : last - 1;
-    ahead_off = INGEST ? src_tab[ka] : obs_tab[ka];
+    ahead_off = INGEST ? caller_source(ka) : obs_tab[ka];
   }
   int64_t cpt_next_off = cpt_tab[first + 1 < last ? first + 1 : first];
   T cpt_cur[E];
@@ -282,18 +281,14 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     if constexpr (INGEST_STATES) {
       nxt_pair = states_pair(first + in);
     } else {
-#ifdef BN_X_NODMA
-      if (false) {
-#else
       if (i + R < n) {
-#endif
         // the slot of family i is free once its evidence is in registers
 #pragma unroll
         for (int32_t j = 0; j < S; ++j) asm volatile("" ::"v"(cur_ev[j]));
         const void* source = INGEST ? reinterpret_cast<const void*>(ahead_off) : static_cast<const void*>(arena + ahead_off);
         request(source, i % R);
         const int32_t ka = k + R + 1 < last ? k + R + 1 : last - 1;
-        ahead_off = INGEST ? src_tab[ka] : obs_tab[ka];
+        ahead_off = INGEST ? caller_source(ka) : obs_tab[ka];
         // family i + 1 must have arrived.  Younger than its DMAs are, in the steady state, R - 1
         // families' worth of operations; during the first R - 1 iterations fewer of the other
         // operations have been issued, and only the DMAs can be relied on to be there
@@ -336,11 +331,6 @@ __global__ void __launch_bounds__(256) leaf_loop_p1(T* __restrict__ arena, const
     // the leaf's next normaliser z' = sum_i t_i q_i with t = r / sum r, r = P' / (previous message
     // to the parent); in the steady state r = P' / q and z' = sum(P') / sum(r)
     fv<T, V> zn;
-#ifdef BN_X_NOCOMPUTE
-    if constexpr (!PROD) {
-      zn = cur_ev[0] + cur_ev[1];
-    } else
-#endif
     if constexpr (!PROD) {
       fv<T, V> sum_r = splat<T, V>(0.f);
 #pragma unroll

@@ -271,6 +271,9 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
  * before anything is queried.  Same kernels and results as the separate calls; the point is the
  * number of host calls and launches per step, which is what bounds small batches (see
  * bn_plan_enable_step_graphs: this sequence, M-step included, runs as one captured graph).
+ * Residency: the evidence arrays are read by kernels of this call on `stream` until its last launch
+ * has run (the plan's own copy would be void after the step, so a step may not make one at all):
+ * they must stay unchanged until then, as any stream-ordered input.
  */
 int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
                double off_value, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
