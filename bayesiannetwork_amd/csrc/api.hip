@@ -1591,6 +1591,40 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
   return rc;
 }
 
+// Evidence of a whole-step call (bn_em_step, bn_em_step_statistics): read by the first iteration itself
+// where bn_em_statistics_from[_states] would do so, and - the plan being reset when the call ends - by
+// every launch from the caller's arrays where the kernels for that exist (no copy at all).
+static int step_evidence(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
+                  double off_value, int32_t num_iterations, void* stream) {
+  bn::Plan& p = plan->p;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bool ingest = !p.observed.empty() && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0;
+  if (ingest && states_dev) {
+    ingest = reinterpret_cast<uintptr_t>(states_dev) % 2 == 0 && bn::ingest_states_possible(p);
+  } else if (ingest) {
+    ingest = bn::ingest_possible(p);
+    for (size_t i = 0; i < p.observed.size() && ingest; ++i)
+      ingest = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
+  }
+  if (!ingest) {
+    const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
+                              : bn_enter_evidence(plan, evidence_dev, stream);
+    if (rc != BN_OK) return rc;
+  } else {
+    const bool graphs_possible = step_graphs_enabled() && plan->graphs_wanted && !plan->graphs_off;
+    if (int rc = upload_family_sources(p, states_dev ? nullptr : evidence_dev, s, states_dev, !graphs_possible)) return rc;
+    p.obs_pending = false;  // the first factor pass writes every observation array
+    if (states_dev) {
+      bn::set_ingest_next(p, true, true, on_value, off_value);
+    } else {
+      bn::set_ingest_next(p, true);
+      // the plan is reset when the step ends: nothing would ever read its copy of the evidence
+      bn::set_evidence_in_caller(p, bn::caller_evidence_possible(p, num_iterations));
+    }
+  }
+  return settle_observations(p, s);
+}
+
 int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
                double off_value, int32_t num_iterations, int32_t average, double learning_rate, double regularization,
                double* ll_out_dev, void* new_cpts_dev, void* stream) {
@@ -1642,32 +1676,7 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
       plan->star.ok = false;  // the runtime refused the cooperative launch: launch per pass from now on
     }
   }
-  // evidence: read by the first iteration itself where bn_em_statistics_from[_states] would do so
-  bool ingest = !p.observed.empty() && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0;
-  if (ingest && states_dev) {
-    ingest = reinterpret_cast<uintptr_t>(states_dev) % 2 == 0 && bn::ingest_states_possible(p);
-  } else if (ingest) {
-    ingest = bn::ingest_possible(p);
-    for (size_t i = 0; i < p.observed.size() && ingest; ++i)
-      ingest = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
-  }
-  if (!ingest) {
-    const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
-                              : bn_enter_evidence(plan, evidence_dev, stream);
-    if (rc != BN_OK) return rc;
-  } else {
-    const bool graphs_possible = step_graphs_enabled() && plan->graphs_wanted && !plan->graphs_off;
-    if (int rc = upload_family_sources(p, states_dev ? nullptr : evidence_dev, s, states_dev, !graphs_possible)) return rc;
-    p.obs_pending = false;  // the first factor pass writes every observation array
-    if (states_dev) {
-      bn::set_ingest_next(p, true, true, on_value, off_value);
-    } else {
-      bn::set_ingest_next(p, true);
-      // the plan is reset when the step ends: nothing would ever read its copy of the evidence
-      bn::set_evidence_in_caller(p, bn::caller_evidence_possible(p, num_iterations));
-    }
-  }
-  if (int rc = settle_observations(p, s)) return rc;
+  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream)) return rc;
   if (!plan->accum_slot) {
     BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&plan->accum_slot), (size_t)std::max<int64_t>(p.cpt_total, 1) * sizeof(double)));
     p.device_bytes += p.cpt_total * 8;
@@ -1712,6 +1721,39 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   BN_LAUNCH_CHECK("sum_partials");
   prof_end(s);
   return BN_OK;
+}
+
+int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
+                          double off_value, int32_t num_iterations, int32_t average, double* ll_out_dev,
+                          double* accum_dev, void* stream) {
+  if (!plan || !ll_out_dev || !accum_dev) return fail(BN_ERR_INVALID, "null argument");
+  if (num_iterations < 1) return fail(BN_ERR_INVALID, "num_iterations must be >= 1");
+  bn::Plan& p = plan->p;
+  if (int rc = on_plan_device(p)) return rc;
+  if (!p.cpts_set) return fail(BN_ERR_STATE, "bn_set_cpts has not been called");
+  if (!p.observed.empty() && !evidence_dev && !states_dev) return fail(BN_ERR_INVALID, "no evidence given");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s)) return rc;
+  struct NoGraphs {  // the launches below are not captured (a graph would keep this call's addresses)
+    bn_plan* plan;
+    bool before;
+    ~NoGraphs() { plan->graphs_off = before; }
+  } no_graphs{plan, plan->graphs_off};
+  plan->graphs_off = true;
+  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream)) return rc;
+  int32_t ll_blocks = 0;
+  t_discard_last_messages = true;
+  int rc = statistics_launches(p, num_iterations, 1, accum_dev, s, &ll_blocks);
+  t_discard_last_messages = false;
+  bn::set_ingest_next(p, false);
+  bn::set_evidence_in_caller(p, false);
+  if (rc != BN_OK) return rc;
+  prof_begin("log_likelihood", (double)p.N * 8.0, s);
+  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, average ? 1.0 / (double)p.N : 1.0, ll_out_dev);
+  BN_LAUNCH_CHECK("sum_partials");
+  prof_end(s);
+  // nobody will query this batch's messages: the plan is as after bn_reset_messages
+  return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
 }
 
 int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,

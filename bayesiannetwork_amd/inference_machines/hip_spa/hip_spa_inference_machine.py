@@ -544,6 +544,43 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self.iterations_run = self._num_iterations
         return ll, new
 
+    def em_step_statistics(self, evidence: Evidence, out: Optional[torch.Tensor] = None):
+        """The statistics half of ``em_step`` for runs that add them up over several devices before the
+        M-step: ``(log_likelihood_tensor, expected_count_sums)`` of ``evidence`` on fresh messages,
+        the same values as ``em_statistics(evidence)`` on a new machine.  The engine keeps no copy
+        of the evidence (it is reset when the call ends; the machine re-enters the batch if it is
+        queried afterwards).  ``out``: a float64 buffer of at least ``cpt elements + 1`` entries to
+        write into (count sums first, then the log-likelihood), e.g. the front of the buffer that
+        is all-reduced next, so that nothing has to be copied there."""
+        if not self.can_em_step:
+            raise RuntimeError("em_step_statistics needs plain settings (no callback, no convergence tolerance)")
+        total = self._lib.bn_plan_cpt_elements(self._plan)
+        if out is None:
+            out = torch.empty((total + 1,), device=self._device, dtype=torch.float64)
+        if out.dtype != torch.float64 or out.device != self._device or not out.is_contiguous() or out.numel() < total + 1:
+            raise ValueError("out must be a contiguous float64 tensor on the machine's device with cpt elements + 1 entries")
+        counts, ll = out[:total], out[total : total + 1]
+        average = 1 if self._settings.average_log_likelihood else 0
+        with torch.cuda.device(self._device):
+            if isinstance(evidence, HardEvidence):
+                states = self._hard_states(evidence)
+                keep = states
+                rc = self._lib.bn_em_step_statistics(self._plan, None, ctypes.c_void_p(states.data_ptr()),
+                                                     evidence.on_value, evidence.off_value, self._num_iterations,
+                                                     average, ctypes.c_void_p(ll.data_ptr()),
+                                                     ctypes.c_void_p(counts.data_ptr()), self._stream())
+            else:
+                keep = self._evidence_table(evidence)
+                rc = self._lib.bn_em_step_statistics(self._plan, keep[2], None, 1.0, 0.0, self._num_iterations, average,
+                                                     ctypes.c_void_p(ll.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                                     self._stream())
+            _native.check(rc)
+        self._evidence_keepalive = keep
+        self._evidence_to_restore = evidence
+        self.must_iterate = True
+        self.iterations_run = self._num_iterations
+        return ll, counts
+
     def m_step(self, count_sums: torch.Tensor, old_flat: Optional[torch.Tensor],
                learning_rate: Optional[float], regularization: Optional[float]) -> torch.Tensor:
         """New flat CPT buffer (network order, machine dtype) from flat float64 expected counts:

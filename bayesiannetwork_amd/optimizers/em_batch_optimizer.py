@@ -5,13 +5,14 @@ machine, log-likelihood, expected counts, then
 from __future__ import annotations
 
 from dataclasses import dataclass
+import torch
 from typing import Optional
 
 from ..bayesian_network import BayesianNetwork
 from ..inference_machines.evidence import EvidenceLoader
 from .abstractions import IBatchOptimizer, IEvaluator
 from .common import MachineFactory, OptimizerLogger
-from .em_step import FlatModel, blend, expected_counts, normalise, reduce_statistics, regularise
+from .em_step import FlatModel, blend, expected_counts, normalise, reduce_packed, reduce_statistics, regularise
 
 
 @dataclass(frozen=True)
@@ -54,6 +55,27 @@ class EmBatchOptimizer(IBatchOptimizer):
                     flat_model.assign(flat)
                     # back to the pool before the next machine is built: that one then gets this very
                     # plan, which already holds the new parameters
+                    machine = None
+                    if not deferred:
+                        ll = ll.item()
+                    if deferred:
+                        pending.append((iteration, ll))
+                    elif self._logger:
+                        self._logger.log(epoch, iteration, ll)
+                    if self._evaluator:
+                        self._evaluator.evaluate(epoch, iteration, self._network)
+                    continue
+                if cfg.sharded and getattr(machine, "can_em_step", False) and hasattr(machine, "em_step_statistics"):
+                    # sharded run: this rank's statistics in one engine call, written straight into the
+                    # buffer that is all-reduced; then the same M-step on every rank
+                    if flat_model is None:
+                        flat_model = FlatModel.of(self._network)
+                    flat = flat_model.gather()
+                    packed = torch.empty((flat.numel() + 2,), dtype=torch.float64, device=flat.device)
+                    machine.em_step_statistics(evidence, out=packed)
+                    sums, ll, _ = reduce_packed(machine, packed, cfg.sharded)
+                    flat = machine.m_step(sums, flat, cfg.learning_rate, cfg.regularization)
+                    flat_model.assign(flat)
                     machine = None
                     if not deferred:
                         ll = ll.item()

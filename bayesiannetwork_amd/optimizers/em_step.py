@@ -205,6 +205,25 @@ def reduce_statistics(machine, flat_sums: torch.Tensor, ll, sharded: bool):
     return packed[:total], ll_out, n_total
 
 
+def reduce_packed(machine, packed: torch.Tensor, sharded: bool):
+    """``reduce_statistics`` for statistics that already lie in the buffer that is all-reduced:
+    ``packed`` = [expected-count sums..., log-likelihood, (free slot)] as
+    ``machine.em_step_statistics(evidence, out=packed)`` leaves it.  Returns (sums, ll tensor, total N
+    tensor); device-side operations only."""
+    total = packed.numel() - 2
+    n_local = float(max(machine.num_observations, 1))
+    dist = torch.distributed
+    if not (sharded and dist.is_available() and dist.is_initialized()):
+        return packed[:total], packed[total : total + 1], n_local
+    avg = machine.settings.average_log_likelihood
+    if avg:
+        packed[total : total + 1].mul_(n_local)
+    packed[total + 1 :].fill_(n_local)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    ll = packed[total : total + 1] / packed[total + 1] if avg else packed[total : total + 1]
+    return packed[:total], ll, packed[total + 1]
+
+
 def normalise(p_conditional: torch.Tensor) -> torch.Tensor:
     return p_conditional / p_conditional.sum(dim=-1, keepdim=True)
 

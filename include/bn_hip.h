@@ -280,6 +280,21 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
                double* ll_out_dev, void* new_cpts_dev, void* stream);
 
 /*
+ * The statistics half of bn_em_step, for callers that add the sums up over several devices before
+ * the M-step (the loop body of optimizers/em_batch_optimizer.py:37-59 on every rank up to the
+ * E-step's sums, an all-reduce of [count sums, log-likelihood, N] in between, bn_m_step after it):
+ *   bn_reset_messages; evidence as in bn_em_step; num_iterations iterations; *ll_out_dev =
+ *   log-likelihood (mean if average); expected-count sums (flat, network order, float64) to accum_dev.
+ * Afterwards the plan is as after bn_reset_messages (CPT snapshot unchanged): nobody queries the
+ * messages of a batch that is only summed, so - as in bn_em_step - the plan keeps no copy of the
+ * evidence where its kernels can read the caller's arrays directly.  Same residency rule as
+ * bn_em_step; same results as bn_em_statistics_from[_states] on a reset plan.
+ */
+int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
+                          double off_value, int32_t num_iterations, int32_t average, double* ll_out_dev,
+                          double* accum_dev, void* stream);
+
+/*
  * M-step for the whole network in one launch.  For every CPT row (last axis) of every node:
  *   target = count_sums_row / sum(count_sums_row)
  *   target = (1 - regularization) * target + regularization / num_states      if regularization != 0

@@ -25,6 +25,12 @@ class OracleMachine(IInferenceMachine):
             self.expected_count_sums = self._expected_count_sums
             self.split_counts = self._split_counts
             self.log_likelihood_tensor = lambda: torch.tensor([self.log_likelihood()], dtype=torch.float64)
+        if with_count_sums == "step":
+            # ... and its whole-step surface (statistics written into the caller's packed buffer)
+            self.can_em_step = True
+            self.em_step_statistics = self._em_step_statistics
+            self.em_step = self._em_step
+            self.m_step = self._m_step
 
     @property
     def settings(self):
@@ -53,3 +59,24 @@ class OracleMachine(IInferenceMachine):
             out.append(flat[pos:pos + size].reshape(node.cpt.shape))
             pos += size
         return out
+
+    def _em_step_statistics(self, evidence, out=None):
+        self.enter_evidence(evidence)
+        counts = self._expected_count_sums()
+        if out is None:
+            out = torch.empty((counts.numel() + 1,), dtype=torch.float64)
+        out[:counts.numel()] = counts
+        out[counts.numel()] = self.log_likelihood()
+        return out[counts.numel():counts.numel() + 1], out[:counts.numel()]
+
+    def _m_step(self, count_sums, old_flat, learning_rate, regularization):
+        from bayesiannetwork_amd.optimizers.em_step import FlatModel
+
+        return FlatModel.of(self._network).m_step(count_sums, old_flat, learning_rate, regularization)
+
+    def _em_step(self, evidence, learning_rate, regularization):
+        from bayesiannetwork_amd.optimizers.em_step import FlatModel
+
+        ll, counts = self._em_step_statistics(evidence)
+        old = FlatModel.of(self._network).gather()
+        return ll.clone(), self._m_step(counts, old, learning_rate, regularization)

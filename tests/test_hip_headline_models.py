@@ -434,3 +434,59 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
     assert abs(ll2.item() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
     for j, got in enumerate(second.split_counts(flat2)):
         _check(got, want_counts[j], f"counts {nodes[j].name}", f32)
+
+
+@pytest.mark.parametrize("layout", ["slices of one buffer", "separate arrays"])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layout):
+    """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 distinct soft + hard rows
+    (five observation tiles, a ragged last one; evidence arrays as equally spaced slices of one buffer,
+    which the engine then reads where they lie in every launch, and as separately allocated arrays,
+    which it copies into the plan): the same log-likelihood, count sums and new parameters, bit for
+    bit, as ``em_statistics(evidence)`` + ``m_step`` on a machine of its own, and the same answers
+    when the machines are queried afterwards."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+
+    n = 1026
+    ts, network, ys = _leaf_model("c3a", dtype, "cuda")
+    rows = _mixed_evidence(n, len(ys), 21, ts.dtype)
+    if layout == "slices of one buffer":
+        tensors = list(torch.stack(rows).cuda().unbind(0))
+    else:
+        tensors = [r.cuda().clone() for r in rows]
+    settings = SpaInferenceMachineSettings(ts, True)
+    model = FlatModel.of(network)
+    model.assign(model.gather())
+    old = model.gather().clone()
+
+    def machine_for():
+        machine = HipSpaInferenceMachine(settings, network, ys, n)
+        machine.enable_star_step(False)
+        return machine
+
+    plain = machine_for()
+    want_ll, want_counts = plain.em_statistics(Evidence(tensors, ts))
+    want_new = plain.m_step(want_counts, old, 0.2, 0.01)
+
+    summed = machine_for()
+    packed = torch.full((want_counts.numel() + 2,), -1.0, dtype=torch.float64, device="cuda")
+    ll, counts = summed.em_step_statistics(Evidence(tensors, ts), out=packed)
+    assert torch.equal(ll, want_ll) and torch.equal(counts, want_counts)
+    assert counts.data_ptr() == packed.data_ptr() and packed[-1].item() == -1.0
+    q = list(network.nodes)[0]
+    for a, b in zip(summed.infer_single_nodes([q, ys[5]]), plain.infer_single_nodes([q, ys[5]])):
+        assert torch.equal(a, b)
+    assert torch.equal(summed.observation(ys[700]), tensors[700])
+
+    stepped = machine_for()
+    ll, new = stepped.em_step(Evidence(tensors, ts), 0.2, 0.01)
+    assert torch.equal(ll, want_ll) and torch.equal(new, want_new)
+    # asked after its step, the machine answers for the batch under the NEW parameters
+    model.assign(new)
+    fresh = machine_for()
+    fresh.enter_evidence(Evidence(tensors, ts))
+    for a, b in zip(stepped.infer_nodes_with_parents([ys[3]]), fresh.infer_nodes_with_parents([ys[3]])):
+        assert torch.equal(a, b)
+    assert stepped.log_likelihood() == fresh.log_likelihood()

@@ -124,10 +124,10 @@ def _sharded_worker(rank, world, port, name, fast_surface, out_dir):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("fast_surface", [False, True])
+@pytest.mark.parametrize("fast_surface", [False, True, "step"])
 def test_two_rank_sharded_em_equals_single_process(tmp_path, fast_surface):
     name = "em_batch_c3a_mini16_f64"
-    port = 29500 + (os.getpid() % 2000) + (1 if fast_surface else 0)
+    port = 29500 + (os.getpid() % 2000) + {False: 0, True: 1, "step": 2}[fast_surface]
     mp.spawn(_sharded_worker, args=(2, port, name, fast_surface, str(tmp_path)), nprocs=2, join=True)
 
     fx = Fixture(name)
