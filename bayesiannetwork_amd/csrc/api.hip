@@ -608,13 +608,11 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
   }
   prof_begin("em_finalize", 0.0, s);
   bn::FastState* st = bn::fast_state(p);
+  bn::ListedEntries listed{nullptr, nullptr, 0, 0};
   if (st && !st->fused.empty() && reduced_groups.size() == st->fused.size()) {
-    // every fused group brings its own counts: only the other nodes' entries went through `partial`
-    if (st->n_unfused_entries > 0) {
-      bn::launch(bn::em_finalize_listed<T>, dim3((uint32_t)((st->n_unfused_entries + 3) / 4)), dim3(256), 0, s,
-                 partial, cpts, st->d_unfused_entries, st->n_unfused_entries, nchunks, accum);
-      BN_LAUNCH_CHECK("em_finalize_listed");
-    }
+    // every fused group brings its own counts: only the other nodes' entries went through `partial`;
+    // they are finalised by the first group's launch below
+    if (st->n_unfused_entries > 0) listed = bn::ListedEntries{partial, st->d_unfused_entries, st->n_unfused_entries, nchunks};
   } else {
     bn::launch(bn::em_finalize<T>, dim3((uint32_t)((p.cpt_total + 255) / 256)), dim3(256), 0, s, partial,
                        cpts, p.cpt_total, nchunks, accum);
@@ -623,8 +621,9 @@ int em_accumulate_t(bn::Plan& p, double* accum, bool use_reduced, hipStream_t s)
   prof_end(s);
   for (const bn::FactorGroup* g : reduced_groups) {
     prof_begin(flabel("em_counts(from leaf_family sums)", *g), 0.0, s);
-    if (bn::finalize_em_fast(p, (size_t)(g - p.fgroups.data()), accum, s) <= 0)
+    if (bn::finalize_em_fast(p, (size_t)(g - p.fgroups.data()), accum, s, listed) <= 0)
       return fail(BN_ERR_HIP, "launch of em_finalize_slots failed");
+    listed.count = 0;
     prof_end(s);
   }
   return BN_OK;
@@ -1686,6 +1685,10 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   key.append(reinterpret_cast<const char*>(&regularization), sizeof regularization);
   bool from_graph = false;
   int32_t ll_blocks = 0;
+  // the M-step launch also sums the log-likelihood partials into the caller's slot (not when it runs
+  // from a graph: the caller's address may differ from call to call)
+  bool ll_written = false;
+  const double ll_scale = average ? 1.0 / (double)p.N : 1.0;
   const int rc = run_sequence(
       plan, key, num_iterations, s, &from_graph, &ll_blocks, [&](hipStream_t on, bool in_graph, int32_t* blocks) {
         t_discard_last_messages = true;
@@ -1699,12 +1702,15 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
         if (p.dtype == BN_F32) {
           bn::launch(bn::m_step_rows<float>, grid, dim3(256), 0, on, (const double*)plan->accum_slot,
                      static_cast<const float*>(p.cpts), p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization,
-                     static_cast<float*>(p.cpts), in_graph ? nullptr : static_cast<float*>(new_cpts_dev));
+                     static_cast<float*>(p.cpts), in_graph ? nullptr : static_cast<float*>(new_cpts_dev),
+                     (const double*)p.scratch, *blocks, ll_scale, in_graph ? nullptr : ll_out_dev);
         } else {
           bn::launch(bn::m_step_rows<double>, grid, dim3(256), 0, on, (const double*)plan->accum_slot,
                      static_cast<const double*>(p.cpts), p.d_row_off, p.d_row_len, p.n_rows, learning_rate,
-                     regularization, static_cast<double*>(p.cpts), in_graph ? nullptr : static_cast<double*>(new_cpts_dev));
+                     regularization, static_cast<double*>(p.cpts), in_graph ? nullptr : static_cast<double*>(new_cpts_dev),
+                     (const double*)p.scratch, *blocks, ll_scale, in_graph ? nullptr : ll_out_dev);
         }
+        ll_written = !in_graph;
         BN_LAUNCH_CHECK("m_step_rows");
         prof_end(on);
         // with new parameters every stored message is stale: the plan is as after bn_set_cpts + bn_reset_messages
@@ -1716,10 +1722,12 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   if (rc != BN_OK) return rc;
   if (from_graph)
     BN_HIP_CHECK(hipMemcpyAsync(new_cpts_dev, p.cpts, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice, s));
-  prof_begin("log_likelihood", (double)p.N * 8.0, s);
-  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, average ? 1.0 / (double)p.N : 1.0, ll_out_dev);
-  BN_LAUNCH_CHECK("sum_partials");
-  prof_end(s);
+  if (!ll_written) {
+    prof_begin("log_likelihood", (double)p.N * 8.0, s);
+    bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, ll_scale, ll_out_dev);
+    BN_LAUNCH_CHECK("sum_partials");
+    prof_end(s);
+  }
   return BN_OK;
 }
 
@@ -1769,11 +1777,11 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
   if (p.dtype == BN_F32) {
     bn::launch(bn::m_step_rows<float>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const float*>(old_cpts_dev),
                p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<float*>(new_cpts_dev),
-               static_cast<float*>(nullptr));
+               static_cast<float*>(nullptr), static_cast<const double*>(nullptr), 0, 1.0, static_cast<double*>(nullptr));
   } else {
     bn::launch(bn::m_step_rows<double>, grid, dim3(256), 0, s, count_sums_dev, static_cast<const double*>(old_cpts_dev),
                p.d_row_off, p.d_row_len, p.n_rows, learning_rate, regularization, static_cast<double*>(new_cpts_dev),
-               static_cast<double*>(nullptr));
+               static_cast<double*>(nullptr), static_cast<const double*>(nullptr), 0, 1.0, static_cast<double*>(nullptr));
   }
   BN_LAUNCH_CHECK("m_step_rows");
   prof_end(s);

@@ -962,21 +962,23 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
 }
 
 // EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.
-inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s) {
+// listed: other entries to finalise from their chunk partial sums in the same launch (count 0 = none).
+inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s, ListedEntries listed = ListedEntries{nullptr, nullptr, 0, 0}) {
   FastState* st = fast_state(p);
   if (!st) return 0;
   auto it = st->fused.find((int32_t)fi);
   if (it == st->fused.end() || !it->second.em_ready) return 0;
   FactorGroup& g = p.fgroups[fi];
   const int64_t items = (int64_t)g.nodes.size() * g.cpt_elems;
+  const uint32_t blocks = wave_blocks(items) + (uint32_t)((listed.count + kWavesPerBlock - 1) / kWavesPerBlock);
   if (p.dtype == 0) {
-    launch(em_finalize_slots<float>, dim3(wave_blocks(items)), dim3(256), 0, s,
+    launch(em_finalize_slots<float>, dim3(blocks), dim3(256), 0, s,
            static_cast<const float*>(it->second.em_partial), static_cast<const float*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed);
   } else {
-    launch(em_finalize_slots<double>, dim3(wave_blocks(items)), dim3(256), 0, s,
+    launch(em_finalize_slots<double>, dim3(blocks), dim3(256), 0, s,
            static_cast<const double*>(it->second.em_partial), static_cast<const double*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed);
   }
   return launch_ok() ? 1 : -1;
 }

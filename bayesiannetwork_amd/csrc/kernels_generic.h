@@ -486,34 +486,51 @@ __global__ void __launch_bounds__(256) ll_partial(const T* __restrict__ c, int64
 
 // M-step, one thread per CPT row.  Products and sums are kept separate (no fused multiply-add),
 // so the result is the one the same formulas give when evaluated operation by operation.
+// ll_out != nullptr: block 0 also adds up `ll_count` partial sums of the log-likelihood exactly as
+// sum_partials does (same association) and writes ll_scale times the total there - the last launch
+// of an EM step then delivers both results.
 template <typename T>
 __global__ void __launch_bounds__(256) m_step_rows(const double* __restrict__ counts, const T* old_cpts,
                                                   const int64_t* __restrict__ row_off,
                                                   const int32_t* __restrict__ row_len, int64_t rows,
-                                                  double learning_rate, double regularization, T* out, T* out2) {
+                                                  double learning_rate, double regularization, T* out, T* out2,
+                                                  const double* __restrict__ ll_partial, int32_t ll_count,
+                                                  double ll_scale, double* __restrict__ ll_out) {
 #pragma clang fp contract(off)
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows) return;
-  const int64_t off = row_off[r];
-  const int32_t S = row_len[r];
-  double sum = 0.0;
-  for (int32_t j = 0; j < S; ++j) sum += counts[off + j];
-  const double uniform = 1.0 / (double)S;
-  for (int32_t j = 0; j < S; ++j) {
-    double x = counts[off + j] / sum;
-    if (regularization != 0.0) {
-      const double a = (1.0 - regularization) * x;
-      const double b = regularization * uniform;
-      x = a + b;
+  if (r < rows) {
+    const int64_t off = row_off[r];
+    const int32_t S = row_len[r];
+    double sum = 0.0;
+    for (int32_t j = 0; j < S; ++j) sum += counts[off + j];
+    const double uniform = 1.0 / (double)S;
+    for (int32_t j = 0; j < S; ++j) {
+      double x = counts[off + j] / sum;
+      if (regularization != 0.0) {
+        const double a = (1.0 - regularization) * x;
+        const double b = regularization * uniform;
+        x = a + b;
+      }
+      if (learning_rate >= 0.0) {
+        const double a = (1.0 - learning_rate) * (double)old_cpts[off + j];
+        const double b = learning_rate * x;
+        x = a + b;
+      }
+      out[off + j] = (T)x;  // may be old_cpts itself: each entry is read before it is written, by the same thread
+      if (out2) out2[off + j] = (T)x;
     }
-    if (learning_rate >= 0.0) {
-      const double a = (1.0 - learning_rate) * (double)old_cpts[off + j];
-      const double b = learning_rate * x;
-      x = a + b;
-    }
-    out[off + j] = (T)x;  // may be old_cpts itself: each entry is read before it is written, by the same thread
-    if (out2) out2[off + j] = (T)x;
   }
+  if (ll_out == nullptr || blockIdx.x != 0) return;
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int32_t i = threadIdx.x; i < ll_count; i += 256) acc += ll_partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int32_t step = 128; step > 0; step >>= 1) {
+    if ((int32_t)threadIdx.x < step) red[threadIdx.x] += red[threadIdx.x + step];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ll_out[0] = red[0] * ll_scale;
 }
 
 // Same sum when part of it already exists as per-observation partial sums: adds the normalisers

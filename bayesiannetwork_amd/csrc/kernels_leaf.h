@@ -380,6 +380,13 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
   WaveSums<T, D0 * S> held;
   T* held_dst = nullptr;
 
+  constexpr bool kCptAhead = REDUCE && D0 * S <= 24;
+  T cpt_held[kCptAhead ? D0 * S : 1];
+  if constexpr (kCptAhead) {
+    const T* c = cpts + a.cpt_off[first];
+#pragma unroll
+    for (int32_t j = 0; j < D0 * S; ++j) cpt_held[j] = c[j];
+  }
   // kDeep: the loop state is requested two families ahead instead of one (where the registers allow:
   // the launch that reads the caller's arrays, which keeps no addresses per family)
   constexpr bool kDeep = CALLER;
@@ -402,7 +409,15 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
       ptr_mid = ptr_far;
       mid = far;
     }
-    const T* cpt = ptr.cpt;
+    // CPT rows: small ones travel one family ahead through the scalar cache (requested here for the
+    // next family, the current family's were requested a turn ago), so that no family starts by
+    // waiting for its scalar loads
+    T cpt_next[kCptAhead ? D0 * S : 1];
+    if constexpr (kCptAhead) {
+#pragma unroll
+      for (int32_t j = 0; j < D0 * S; ++j) cpt_next[j] = ptr_next.cpt[j];
+    }
+    const T* cpt = kCptAhead ? cpt_held : ptr.cpt;
 
     // q = cpt . ev.  The leaf's message to the factor is ev / z, so the factor's message to the
     // parent is q / z; and because the parent's message back is normalised over its states, q
@@ -511,6 +526,10 @@ __global__ void __launch_bounds__(256) leaf_family_p1(T* __restrict__ arena, con
           held = sums;
           held_dst = dst;
         }
+      }
+      if constexpr (kCptAhead) {
+#pragma unroll
+        for (int32_t j = 0; j < D0 * S; ++j) cpt_held[j] = cpt_next[j];
       }
       ptr = ptr_next;
       cur = nxt;
@@ -944,15 +963,38 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
 }
 
 // accum[entry] = cpt[entry] * sum over the per-wave sums written by the kLeafReduce kernel.
-// One wave per CPT entry.   grid.x = ceil(entries / 4), block = 256
+// One wave per CPT entry.   grid.x = ceil(entries / 4) (+ ceil(listed.count / 4)), block = 256
+// The blocks past the group's own also finalise a list of other entries from their chunk partial
+// sums (em_finalize_listed's work: the entries no fused group delivers), so that an EM step of a
+// network with a few unfused nodes needs one finalising launch, not two.
+struct ListedEntries {
+  const double* partial;   // [entry][nchunks]
+  const int32_t* entries;  // [count] flat CPT positions
+  int32_t count;           // 0 = none
+  int32_t nchunks;
+};
+
 template <typename T>
 __global__ void __launch_bounds__(256) em_finalize_slots(const T* __restrict__ em_partial,
                                                         const T* __restrict__ cpts,
                                                         const int64_t* __restrict__ cpt_off, int32_t K,
                                                         int32_t entries_per_node, int32_t slots,
-                                                        double* __restrict__ accum) {
+                                                        double* __restrict__ accum, ListedEntries listed) {
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t own = (((int64_t)K * entries_per_node + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+  if (item >= own) {
+    const int64_t i = item - own;
+    if (i >= listed.count) return;
+    const int64_t e = listed.entries[i];
+    // fixed association: lane l sums chunks l, l + 64, ..; then the butterfly
+    double acc = 0.0;
+    for (int32_t c = lane; c < listed.nchunks; c += 64) acc += listed.partial[e * listed.nchunks + c];
+#pragma unroll
+    for (int32_t off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) accum[e] = acc * (double)cpts[e];
+    return;
+  }
   if (item >= (int64_t)K * entries_per_node) return;
   const int32_t k = (int32_t)(item / entries_per_node);
   const int32_t e = (int32_t)(item % entries_per_node);
