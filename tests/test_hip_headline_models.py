@@ -490,3 +490,51 @@ def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layou
     for a, b in zip(stepped.infer_nodes_with_parents([ys[3]]), fresh.infer_nodes_with_parents([ys[3]])):
         assert torch.equal(a, b)
     assert stepped.log_likelihood() == fresh.log_likelihood()
+
+
+@pytest.mark.parametrize("iterations", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_784_leaf_model_at_iteration_counts_around_the_diameter(iterations, dtype):
+    """The launch sequence of the fused leaf families depends on the number of iterations (the first
+    loop launch forms the per-state products, later ones only the normalisers' chunk products, the
+    one before a reduce launch is folded into it from three iterations on, a full launch is fed
+    per-family normalisers): 1, 2, 3, 5 and 6 iterations (the diameter is 4) against the float64
+    oracle run for the same number, through the three statistics routes and the query route, at
+    514 observations (an even number, three tiles)."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    n = 514
+    f32 = dtype == "float32"
+    ts, network, ys = _leaf_model("c3a", dtype, "cuda")
+    rows = _mixed_evidence(n, len(ys), 33, ts.dtype)
+    tensors = list(torch.stack(rows).cuda().unbind(0))
+    oracle = _oracle_for("c3a", network, ys, dtype, n, iterations, False, rows)
+    want_ll = oracle.log_likelihood(False)
+    nodes = list(network.nodes)
+    want_counts = [oracle.infer_family(j).sum(dim=0) for j in range(len(nodes))]
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations)
+    limit = (1e-5 if f32 else 1e-9) * abs(want_ll)
+
+    def check_statistics(machine, ll, flat, route):
+        assert abs(ll.item() - want_ll) <= limit, (route, ll.item(), want_ll)
+        for j, got in enumerate(machine.split_counts(flat)):
+            _check(got, want_counts[j], f"{route}: counts {nodes[j].name}", f32)
+
+    machine = HipSpaInferenceMachine(settings, network, ys, n)
+    machine.enable_star_step(False)
+    check_statistics(machine, *machine.em_statistics(Evidence(tensors, ts)), "statistics")
+    _check(machine.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), "single Q after statistics", f32)
+    _check(machine.infer_nodes_with_parents([ys[9]])[0], oracle.infer_family(10), "family after statistics", f32)
+
+    summed = HipSpaInferenceMachine(settings, network, ys, n)
+    summed.enable_star_step(False)
+    check_statistics(summed, *summed.em_step_statistics(Evidence(tensors, ts)), "step statistics")
+    _check(summed.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), "single Q after step statistics", f32)
+
+    queried = HipSpaInferenceMachine(settings, network, ys, n)
+    queried.enter_evidence(Evidence(tensors, ts))
+    assert abs(queried.log_likelihood() - want_ll) <= limit
+    _check(queried.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), "single Q", f32)
+    for j, got in enumerate(queried.split_counts(queried.expected_count_sums())):
+        _check(got, want_counts[j], f"query route: counts {nodes[j].name}", f32)
