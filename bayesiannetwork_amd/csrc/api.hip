@@ -512,7 +512,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
       }
       if (p.lazy_unmapped() && bn::variable_needs_arrays(p, (size_t)(&g - p.vgroups.data()), fresh))
         if (int rc = ensure_message_arrays(p)) return rc;
-      int rc = bn::launch_variable_fast<T>(p, g, arena, fresh, s);
+      int rc = bn::launch_variable_fast<T>(p, g, arena, fresh, s, it == 0 ? 1 : 0, reduce_last != 0 && it == iterations - 2);
       if (rc < 0) return fail(BN_ERR_HIP, "launch of a specialised variable kernel failed");
       if (rc == 0) {
         const int64_t blocks = (int64_t)K * p.ntiles * subs;

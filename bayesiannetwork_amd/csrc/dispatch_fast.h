@@ -90,6 +90,7 @@ inline void invalidate_fast(Plan& p) {
     for (auto& w : st->wide) {
       w.partials_valid = false;
       w.products_cached = false;
+      w.combined_ahead = false;
       // nothing is carried over a reset: the alternating buffers start from the same side every time
       // (a captured launch sequence holds their addresses)
       w.zd_read = 0;
@@ -613,6 +614,9 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   a.prod_mant = w.prod_mant;
   a.prod_exp = w.prod_exp;
   a.prod_mode = (fresh || !w.prod_mant) ? 0 : (w.products_cached ? 2 : 1);
+  a.early_zdiv_mant = nullptr;
+  a.early_zdiv_exp = nullptr;
+  a.early_scaled = nullptr;
   a.scaled = w.scaled_prev;  // the combine writes over the older of the two, then they swap
   a.npad = p.npad;
   a.ntiles = p.ntiles;
@@ -629,10 +633,27 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
 
 template <typename T, int S>
 inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, T* arena, int32_t fresh,
-                             hipStream_t s) {
+                             hipStream_t s, bool next_folds = false) {
+  if (w.combined_ahead) {  // the previous iteration's launch did this combine too
+    w.combined_ahead = false;
+    return true;
+  }
   const bool fused = w.fused_fgroup >= 0;
   if (!fresh && (!fused || !w.partials_valid)) w.products_cached = false;  // the partial products are about to be rebuilt
-  const WideArgs a = wide_args(p, g, w, fresh);
+  WideArgs a = wide_args(p, g, w, fresh);
+  // This iteration's loop launches are all left out (next_folds: the caller checked every fused group
+  // of the node) and nothing else feeds the node but its own parentless factor, whose message does
+  // not change: the next iteration's combine has all its inputs now and runs in this launch.
+  const bool two = next_folds && fused && a.prod_mode == 2 && w.zdiv_mant[0] && p.parents[w.node].empty() &&
+                   w.uncovered.size() == 1 && w.uncovered[0] == w.I - 1 && !env_no_double_combine();
+  if (two) {
+    a.early_zdiv_mant = w.zdiv_mant[w.zd_read];
+    a.early_zdiv_exp = w.zdiv_exp[w.zd_read];
+    a.early_scaled = w.scaled_prev;
+    a.zdiv_mant = w.zdiv_mant[w.zd_read ^ 1];
+    a.zdiv_exp = w.zdiv_exp[w.zd_read ^ 1];
+    a.scaled = w.scaled;  // the older product is not needed any more: no launch reads it
+  }
   if (!fresh && (!fused || !w.partials_valid)) {
     if (w.zdiv_mant[0]) {
       // partial products rebuilt from the stored messages are complete
@@ -669,8 +690,12 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
   }
   if (!launch_ok()) return false;
   if (a.prod_mode == 1) w.products_cached = true;
-  std::swap(w.scaled, w.scaled_prev);
-  if (!fresh && w.zdiv_mant[0]) w.zd_read ^= 1;
+  if (two) {
+    w.combined_ahead = true;  // (two swaps of the scaled products, two flips of the divisor arrays)
+  } else {
+    std::swap(w.scaled, w.scaled_prev);
+    if (!fresh && w.zdiv_mant[0]) w.zd_read ^= 1;
+  }
   if (!fused) {
     if constexpr (std::is_same<T, float>::value) {
       launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
@@ -737,18 +762,24 @@ inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double&
 }
 
 template <typename T>
-int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, hipStream_t s) {
+// last_but_one_before_reduce: this is the iteration before the last one and the last one ends in reduce mode
+int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, hipStream_t s,
+                         int32_t first_iteration = 0, bool last_but_one_before_reduce = false) {
   FastState* st = fast_state(p);
   const size_t gi = (size_t)(&g - p.vgroups.data());
   if (st && st->vgroup_skip[gi]) return 1;  // done inside the leaf-family kernel
   if (st && st->vgroup_wide[gi]) {
     for (int32_t j : g.nodes) {
       WideNode& w = st->wide[st->wide_of_node[j]];
+      // will the factor pass of this iteration leave out every loop launch that feeds this node?
+      bool next_folds = last_but_one_before_reduce && !w.fused_fgroups.empty();
+      for (int32_t fi : w.fused_fgroups)
+        next_folds = next_folds && leaf_launch_folds(st->fused[fi], true, 2, fresh, first_iteration);
       bool ok = false;
       switch (g.num_states) {
-#define X(SV)                                                   \
-  case SV:                                                      \
-    ok = launch_wide_node<T, SV>(p, g, w, arena_t, fresh, s);   \
+#define X(SV)                                                               \
+  case SV:                                                                  \
+    ok = launch_wide_node<T, SV>(p, g, w, arena_t, fresh, s, next_folds);   \
     break;
         BN_SMALL_DIMS(X)
 #undef X

@@ -101,8 +101,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   // One-parent groups: the loop launch of the last but one iteration is left out when a reduce launch
   // follows and this iteration continues from loop state: all it would leave is one z per family,
   // and the reduce launch forms those again from the parent's two scaled products (kLeafRecompute).
-  if (mode == kLeafLoop && !w2 && next_is_last == 2 && !fresh && !first_iteration && fam.z_form == kZPerChunk &&
-      !env_no_recompute()) {
+  if (leaf_launch_folds(fam, mode == kLeafLoop, next_is_last, fresh, first_iteration)) {
     fam.z_form = kZRecompute;
     fam.pending = false;
     fam.em_ready = false;

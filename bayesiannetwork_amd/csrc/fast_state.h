@@ -47,6 +47,9 @@ struct WideNode {
   double* prod_mant = nullptr;  // [S][npad]
   int32_t* prod_exp = nullptr;  // [S][npad]
   bool products_cached = false;
+  // the last combine also did the next iteration's (WideArgs::early_*): that iteration's variable pass
+  // has nothing left to do for this node
+  bool combined_ahead = false;
   bool partials_valid = false;
   // some covered / uncovered slot's message arrays lie in the plan's lazy region
   bool covered_lazy = false, uncovered_lazy = false;
@@ -184,9 +187,23 @@ inline bool env_copy_evidence() {
   static const bool v = getenv("BN_COPY_EVIDENCE") != nullptr;
   return v;
 }
+// BN_NO_DOUBLE_COMBINE=1  every iteration's combine is a launch of its own
+inline bool env_no_double_combine() {
+  static const bool v = getenv("BN_NO_DOUBLE_COMBINE") != nullptr;
+  return v;
+}
 inline bool env_reduce_v2() {
   static const bool v = getenv("BN_REDUCE_V2") != nullptr;
   return v;
+}
+
+// Is the loop launch of a one-parent group left out in this iteration (the reduce launch that follows
+// forms the leaves' normalisers again)?  loop_mode: the launch would be a loop launch; next_is_last:
+// 0, or what the next iteration's launch will be (1 a full launch, 2 a reduce launch).
+inline bool leaf_launch_folds(const FusedFamily& fam, bool loop_mode, int32_t next_is_last, int32_t fresh,
+                              int32_t first_iteration) {
+  return loop_mode && fam.wide_index2 < 0 && next_is_last == 2 && !fresh && !first_iteration &&
+         fam.z_form == kZPerChunk && !env_no_recompute();
 }
 
 }  // namespace bn

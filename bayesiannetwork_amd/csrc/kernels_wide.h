@@ -62,6 +62,14 @@ struct WideArgs {
   double* prod_mant;  // [S][npad]
   int32_t* prod_exp;  // [S][npad]
   int32_t prod_mode;
+  // Two iterations' combines in one launch (prod_mode 2, wide_combine_fast): when no kernel runs
+  // between them (the loop launch in between is folded into the reduce launch that follows) and the
+  // uncovered inputs do not change from one to the next, the launch first forms the earlier
+  // iteration's P' from the stored product and the earlier divisors and writes it to early_scaled
+  // (nothing else of that iteration is ever read), then does the later iteration's whole combine.
+  const double* early_zdiv_mant;  // nullptr = a single combine
+  const int32_t* early_zdiv_exp;
+  double* early_scaled;  // [S][npad]
   double* scaled;     // [S][npad]   P'[s]
   int64_t npad;
   int64_t ntiles;
@@ -73,7 +81,9 @@ struct WideArgs {
 };
 
 // 1 / prod_chunks zdiv for observation n, as a mantissa (0.5, 1] and an exponent
-__device__ __forceinline__ void divisor_product(const WideArgs& a, int64_t n, double& inv_m, int32_t& inv_e) {
+__device__ __forceinline__ void divisor_product(const WideArgs& a, const double* __restrict__ zdiv_mant,
+                                                const int32_t* __restrict__ zdiv_exp, int64_t n, double& inv_m,
+                                                int32_t& inv_e) {
   double m = 1.0;
   int32_t e = 0;
   // mantissas lie in [0.5, 1): sixteen of them multiply without leaving double range
@@ -84,8 +94,8 @@ __device__ __forceinline__ void divisor_product(const WideArgs& a, int64_t n, do
     for (int32_t u = 0; u < 16; ++u) {
       const bool live = ch + u < a.chunks;
       const int64_t at = (int64_t)(live ? ch + u : ch) * a.npad + n;
-      zm[u] = live ? a.zdiv_mant[at] : 1.0;
-      ze[u] = live ? a.zdiv_exp[at] : 0;
+      zm[u] = live ? zdiv_mant[at] : 1.0;
+      ze[u] = live ? zdiv_exp[at] : 0;
     }
 #pragma unroll
     for (int32_t u = 0; u < 16; ++u) {
@@ -203,6 +213,37 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
       e[s] = a.prod_exp[(int64_t)s * a.npad + n];
     }
   }
+  if (stored && wave == 0 && a.early_zdiv_mant) {
+    double m1[S];
+    int32_t e1[S];
+    double inv_m;
+    int32_t inv_e;
+    divisor_product(a, a.early_zdiv_mant, a.early_zdiv_exp, n, inv_m, inv_e);
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      m1[s] = m[s] * inv_m;
+      e1[s] = e[s] + inv_e;
+    }
+    for (int32_t u = 0; u < a.n_uncovered; ++u) {
+      const T* src = arena + a.in_off[a.uncovered[u]] + t * S * tile_of<T>::value + col;
+#pragma unroll
+      for (int32_t s = 0; s < S; ++s) {
+        int de = 0;
+        m1[s] = frexp(m1[s] * (double)src[s * tile_of<T>::value], &de);
+        e1[s] += de;
+      }
+    }
+    int32_t emax1 = kDeadExponent;
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) {
+      int de = 0;
+      m1[s] = frexp(m1[s], &de);
+      e1[s] = m1[s] == 0.0 ? kDeadExponent : e1[s] + de;
+      emax1 = e1[s] > emax1 ? e1[s] : emax1;
+    }
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) a.early_scaled[(int64_t)s * a.npad + n] = ldexp(m1[s], clamp_shift(e1[s] - emax1));
+  }
   for (int32_t ch = wave * 4; ch < (a.fresh || stored ? 0 : a.chunks); ch += nw * 4) {
     double pm[4][S];
     int32_t pe[4][S];
@@ -263,7 +304,7 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
   if (!a.fresh && a.zdiv_mant) {
     double inv_m;
     int32_t inv_e;
-    divisor_product(a, n, inv_m, inv_e);
+    divisor_product(a, a.zdiv_mant, a.zdiv_exp, n, inv_m, inv_e);
 #pragma unroll
     for (int32_t s = 0; s < S; ++s) {
       m[s] *= inv_m;
@@ -386,7 +427,7 @@ __global__ void __launch_bounds__(64 * S) wide_combine_states(T* __restrict__ ar
     if (a.zdiv_mant) {
       double inv_m;
       int32_t inv_e;
-      divisor_product(a, n, inv_m, inv_e);
+      divisor_product(a, a.zdiv_mant, a.zdiv_exp, n, inv_m, inv_e);
       m *= inv_m;
       e += inv_e;
     }
