@@ -617,6 +617,8 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   a.early_zdiv_mant = nullptr;
   a.early_zdiv_exp = nullptr;
   a.early_scaled = nullptr;
+  a.root_cpt = nullptr;
+  a.root_out = 0;
   a.scaled = w.scaled_prev;  // the combine writes over the older of the two, then they swap
   a.npad = p.npad;
   a.ntiles = p.ntiles;
@@ -654,6 +656,18 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
     a.zdiv_exp = w.zdiv_exp[w.zd_read ^ 1];
     a.scaled = w.scaled;  // the older product is not needed any more: no launch reads it
   }
+  // fresh messages, a parentless node whose factor is alone in its group: its message rides along
+  int32_t root_group = -1;
+  if (fresh && fused && p.parents[w.node].empty()) {
+    FastState* st = fast_state(p);
+    const int32_t fi = p.fgroup_of[w.node];
+    const FactorGroup& rg = p.fgroups[fi];
+    if (rg.dims.size() == 1 && rg.nodes.size() == 1 && !st->root_written[fi] && !p.in_lazy(rg.out_off[0])) {
+      a.root_cpt = static_cast<const char*>(p.cpts) + (size_t)rg.cpt_off[0] * p.elem_size;
+      a.root_out = rg.out_off[0];
+      root_group = fi;
+    }
+  }
   if (!fresh && (!fused || !w.partials_valid)) {
     if (w.zdiv_mant[0]) {
       // partial products rebuilt from the stored messages are complete
@@ -690,6 +704,7 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
   }
   if (!launch_ok()) return false;
   if (a.prod_mode == 1) w.products_cached = true;
+  if (root_group >= 0) fast_state(p)->root_written[root_group] = 1;
   if (two) {
     w.combined_ahead = true;  // (two swaps of the scaled products, two flips of the divisor arrays)
   } else {

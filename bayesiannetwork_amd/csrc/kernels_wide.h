@@ -70,6 +70,11 @@ struct WideArgs {
   const double* early_zdiv_mant;  // nullptr = a single combine
   const int32_t* early_zdiv_exp;
   double* early_scaled;  // [S][npad]
+  // A combine on fresh messages (wide_combine_fast) of a parentless node can also write the message of
+  // the node's own factor - the prior, the same for every observation - which nothing reads before
+  // the next combine: the factor pass then has no launch to make for that factor.
+  const void* root_cpt;  // [S] of the plan's element type, nullptr = not wanted
+  int64_t root_out;      // the message array
   double* scaled;     // [S][npad]   P'[s]
   int64_t npad;
   int64_t ntiles;
@@ -212,6 +217,11 @@ __global__ void __launch_bounds__(64 * kCombineMaxWaves) wide_combine_fast(T* __
       m[s] = a.prod_mant[(int64_t)s * a.npad + n];
       e[s] = a.prod_exp[(int64_t)s * a.npad + n];
     }
+  }
+  if (a.fresh && a.root_cpt && wave == 0) {
+    const T* prior = static_cast<const T*>(a.root_cpt);
+#pragma unroll
+    for (int32_t s = 0; s < S; ++s) arena[a.root_out + (t * S + s) * tile_of<T>::value + col] = prior[s];
   }
   if (stored && wave == 0 && a.early_zdiv_mant) {
     double m1[S];
