@@ -436,11 +436,14 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
         _check(got, want_counts[j], f"counts {nodes[j].name}", f32)
 
 
+@pytest.mark.parametrize("n", [1026, 16386])
 @pytest.mark.parametrize("layout", ["slices of one buffer", "separate arrays"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layout):
-    """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 distinct soft + hard rows
-    (five observation tiles, a ragged last one; evidence arrays as equally spaced slices of one buffer,
+def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layout, n):
+    """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 and 16 386 distinct soft +
+    hard rows (five observation tiles, where the waves of a block share a chunk of families in every
+    loop launch, and 65 tiles, where only the later loop launches do; a ragged last tile; evidence
+    arrays as equally spaced slices of one buffer,
     which the engine then reads where they lie in every launch, and as separately allocated arrays,
     which it copies into the plan): the same log-likelihood, count sums and new parameters, bit for
     bit, as ``em_statistics(evidence)`` + ``m_step`` on a machine of its own, and the same answers
@@ -449,7 +452,6 @@ def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layou
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
     from bayesiannetwork_amd.optimizers.em_step import FlatModel
 
-    n = 1026
     ts, network, ys = _leaf_model("c3a", dtype, "cuda")
     rows = _mixed_evidence(n, len(ys), 21, ts.dtype)
     if layout == "slices of one buffer":
