@@ -42,7 +42,7 @@ struct LeafFamilyArgs {
   double* part_mant2;
   int32_t* part_exp2;
   const double* scaled2;
-  T* m_state;  // [K][D0 + D1][npad]
+  T* m_state;  // [K][D0 + D1][npad]  (ratios to each parent's last state: rows D0 - 1 and D0 + D1 - 1 unused)
   // ingesting loop launches only: per family, the caller's evidence array ([N][2], row-major) of its
   // leaf, or the leaf's stand-in observation array in the arena (all ones) when it is not observed
   const void* const* src;
@@ -708,8 +708,9 @@ __global__ void __launch_bounds__(256) wide_product_any(const T* __restrict__ ar
 //   * the factor's previous messages to the parents depend on the other parent's message, so they
 //     cannot be rebuilt from the evidence: the loop state is m1[D0], m2[D1] and the leaf's next z;
 //   * the kernel maintains the chunk partial products of both parents.
-// Per family and observation the loop moves D0+D1+1+S floats in and D0+D1+1 out (7 + 5 for the
-// (2,2,2) families) instead of the 36 of the unfused passes.
+// Per family and observation the loop moves D0+D1-1+S floats in and D0+D1-1 out (5 + 3 for the
+// (2,2,2) families: the loop state holds ratios of the previous messages) instead of the 36 of the
+// unfused passes.
 template <typename T, int N, int V>
 __device__ __forceinline__ void load_scaled(const double* __restrict__ scaled, int64_t npad, fv<T, V>* out) {
 #pragma unroll
@@ -786,10 +787,16 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
 #pragma unroll
     for (int32_t j = 0; j < S; ++j) ev[j] = loadv<T, V>(obs, t * S + j, col);
     if constexpr (STATE == kLeafSteady) {
+      // the parents' messages back are normalised over the states, so of the factor's previous
+      // messages only ratios are kept: (last state's value) / (state i's value), which the quotient
+      // P' / previous message needs as a factor (rows i and D0 + i of the state array; the rows of
+      // the two last states are not used)
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i) prev1[i] = loadv<T, V>(m_state, t * (D0 + D1) + i, col);
+      for (int32_t i = 0; i < D0 - 1; ++i) prev1[i] = loadv<T, V>(m_state, t * (D0 + D1) + i, col);
+      prev1[D0 - 1] = splat<T, V>((T)1);
 #pragma unroll
-      for (int32_t i = 0; i < D1; ++i) prev2[i] = loadv<T, V>(m_state, t * (D0 + D1) + D0 + i, col);
+      for (int32_t i = 0; i < D1 - 1; ++i) prev2[i] = loadv<T, V>(m_state, t * (D0 + D1) + D0 + i, col);
+      prev2[D1 - 1] = splat<T, V>((T)1);
       z = loadv<T, V>(z_state, t, col);
     } else {
       fv<T, V> own[S];
@@ -811,7 +818,7 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
       fv<T, V> sum = splat<T, V>(0.f);
 #pragma unroll
       for (int32_t i = 0; i < D0; ++i) {
-        t1[i] = pf1[i] * rcpv<T, V>(prev1[i]);
+        t1[i] = STATE == kLeafSteady ? pf1[i] * prev1[i] : pf1[i] * rcpv<T, V>(prev1[i]);
         sum += t1[i];
       }
       sum = rcpv<T, V>(sum);
@@ -820,7 +827,7 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
       sum = splat<T, V>(0.f);
 #pragma unroll
       for (int32_t i = 0; i < D1; ++i) {
-        t2[i] = pf2[i] * rcpv<T, V>(prev2[i]);
+        t2[i] = STATE == kLeafSteady ? pf2[i] * prev2[i] : pf2[i] * rcpv<T, V>(prev2[i]);
         sum += t2[i];
       }
       sum = rcpv<T, V>(sum);
@@ -920,10 +927,13 @@ __global__ void __launch_bounds__(256) leaf_family_p2(T* __restrict__ arena, con
         storev<T, V>(f2v_own, t * S + j, col, own[j]);
       }
     } else {
+      // (reciprocals to within an ulp: the next iteration multiplies by the ratio, nothing else is rounded)
 #pragma unroll
-      for (int32_t i = 0; i < D0; ++i) storev<T, V>(m_state, t * (D0 + D1) + i, col, m1[i]);
+      for (int32_t i = 0; i < D0 - 1; ++i)
+        storev<T, V>(m_state, t * (D0 + D1) + i, col, m1[D0 - 1] * recipv<T, V>(m1[i]));
 #pragma unroll
-      for (int32_t i = 0; i < D1; ++i) storev<T, V>(m_state, t * (D0 + D1) + D0 + i, col, m2[i]);
+      for (int32_t i = 0; i < D1 - 1; ++i)
+        storev<T, V>(m_state, t * (D0 + D1) + D0 + i, col, m2[D1 - 1] * recipv<T, V>(m2[i]));
       storev<T, V>(z_state, t, col, leaf_normaliser<T, S, V>(ev, own));
     }
     // fold into both parents' partial products
