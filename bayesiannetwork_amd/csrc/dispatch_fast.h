@@ -294,7 +294,7 @@ inline int prepare_fast(Plan& p) {
     const FactorGroup& g = p.fgroups[fi];
     const int32_t num_parents = (int32_t)g.dims.size() - 1;
     if (num_parents == 2) {
-      if (g.dims[0] != 2 || g.dims[1] != 2 || g.dims[2] != 2) continue;  // the instantiated two-parent shape
+      if (!two_parent_shape(g.dims[0], g.dims[1], g.dims[2])) continue;  // the instantiated two-parent shapes
     } else if (num_parents != 1 || !small_dim(g.dims[0]) || !small_dim(g.dims[1])) {
       continue;
     }

@@ -93,6 +93,16 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
   return nullptr;
 }
 
+// two-parent families: the kernel of a (D0, D1, S) shape, nullptr for a shape without one
+template <typename T, int MODE>
+inline LeafFamilyFn<T> leaf_family_p2_lookup(int32_t d0, int32_t d1, int32_t s) {
+#define X(A, B, C) \
+  if (d0 == A && d1 == B && s == C) return leaf_family_p2<T, A, B, C, kLeafVec, MODE>;
+  BN_TWO_PARENT_SHAPES(X)
+#undef X
+  return nullptr;
+}
+
 // w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
 template <typename T>
 int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena, const T* cpts,
@@ -159,7 +169,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     switch (mode + 3 * state) {
 #define X(M) \
   case M:    \
-    fn = leaf_family_p2<T, 2, 2, 2, kLeafVec, M>; \
+    fn = leaf_family_p2_lookup<T, M>(g.dims[0], g.dims[1], g.dims[2]); \
     break;
       X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X

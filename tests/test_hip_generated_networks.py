@@ -43,6 +43,20 @@ def _two_parent_loopy(gen):
     return spec, observed, 6, True
 
 
+TWO_PARENT_SHAPES = [(2, 2, 3), (2, 2, 4), (2, 3, 2), (3, 2, 2), (2, 3, 3), (3, 2, 3), (3, 3, 2), (3, 3, 3), (4, 4, 2)]
+
+
+def _two_parent_shape(d0, d1, s):
+    """Q(3) -> F1(d0), F2(d1) -> 28 leaves (s | F1, F2), every fifth leaf unobserved; T = 5."""
+    def case(gen):
+        spec = [("Q", (3,), []), ("F1", (3, d0), ["Q"]), ("F2", (3, d1), ["Q"])]
+        for i in range(28):
+            spec.append((f"Y{i}", (d0, d1, s), ["F1", "F2"]))
+        observed = [f"Y{i}" for i in range(28) if i % 5 != 0]
+        return spec, observed, 5, True
+    return case
+
+
 def _many_state_tree(gen):
     """Root(32) -> two hidden 32-state nodes -> one observed 32-state leaf each, plus a 5-state observed child of the root."""
     spec = [("R", (32,), []), ("H0", (32, 32), ["R"]), ("H1", (32, 32), ["R"]), ("Y0", (32, 32), ["H0"]),
@@ -67,6 +81,7 @@ CASES = {
     "many_state_tree": _many_state_tree,
     "two_wide_parents": _deep_chain_with_wide_node,
 }
+CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
 def _build(name, dtype, n):
@@ -216,3 +231,33 @@ def test_several_fused_groups_at_large_batches(name, dtype, n):
         want = oracle.infer_family(j).sum(dim=0).numpy()
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5 if f32 else 1e-9,
                                    atol=(1e-7 if f32 else 1e-11) * float(np.max(np.abs(want))))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("shape", [(2, 2, 2)] + TWO_PARENT_SHAPES)
+def test_two_parent_shapes_run_on_the_fused_kernel(shape, dtype):
+    """The oracle comparisons above pass on whichever kernels serve a network; this one checks that
+    every two-parent leaf-family shape listed has the fused kernel as its route."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.inference_machines.hip_spa.hip_spa_inference_machine import enable_profiling, profile_report
+
+    d0, d1, s = shape
+    name = f"two_parent_{d0}x{d1}x{s}"
+    CASES.setdefault(name, _two_parent_shape(d0, d1, s))
+    n = 300
+    spec, observed_names, iterations, loops, cpts, evidence, make = _build(name, dtype, n)
+    ts, network, by_name = make("cuda", dtype)
+    observed = [by_name[o] for o in observed_names]
+    machine = HipSpaInferenceMachine(
+        SpaInferenceMachineSettings(ts, False, num_iterations=iterations, allow_loops=loops), network, observed, n)
+    machine.enter_evidence(Evidence([evidence[o].to(ts.dtype).to("cuda") for o in observed_names], ts))
+    enable_profiling(True)
+    try:
+        profile_report()
+        machine.log_likelihood()
+        report = profile_report()
+    finally:
+        enable_profiling(False)
+    label = f"leaf_family[{d0}x{d1}x{s},K=28]"
+    assert sum(r["launches"] for r in report if r["kernel"] == label) >= 1, report
