@@ -34,8 +34,19 @@ inline bool small_dim(int32_t d) {
   return false;
 }
 
+inline bool parent_dim(int32_t d) {
+  switch (d) {
+#define X(V) \
+  case V:    \
+    return true;
+    BN_PARENT_DIMS(X)
+#undef X
+  }
+  return false;
+}
+
 inline bool is_wide_group(const Plan& p, const VariableGroup& g) {
-  return g.num_inputs > kWideFanIn && small_dim(g.num_states);
+  return g.num_inputs > kWideFanIn && parent_dim(g.num_states);
 }
 
 template <typename U>
@@ -295,7 +306,7 @@ inline int prepare_fast(Plan& p) {
     const int32_t num_parents = (int32_t)g.dims.size() - 1;
     if (num_parents == 2) {
       if (!two_parent_shape(g.dims[0], g.dims[1], g.dims[2])) continue;  // the instantiated two-parent shapes
-    } else if (num_parents != 1 || !small_dim(g.dims[0]) || !small_dim(g.dims[1])) {
+    } else if (num_parents != 1 || !parent_dim(g.dims[0]) || !small_dim(g.dims[1])) {
       continue;
     }
     const std::vector<int32_t>& family_parents = p.parents[g.nodes[0]];
@@ -796,7 +807,7 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
   case SV:                                                                  \
     ok = launch_wide_node<T, SV>(p, g, w, arena_t, fresh, s, next_folds);   \
     break;
-        BN_SMALL_DIMS(X)
+        BN_PARENT_DIMS(X)
 #undef X
       }
       if (!ok) return -1;

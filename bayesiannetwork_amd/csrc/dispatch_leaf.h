@@ -62,7 +62,7 @@ inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s, bool split) {
 #define X(DV) \
   case DV:    \
     return leaf_loop_for_s<T, DV, OUT, STATE>(s, split);
-    BN_SMALL_DIMS(X)
+    BN_PARENT_DIMS(X)
 #undef X
   }
   return {};
@@ -75,7 +75,7 @@ inline LeafFamilyFn<T> leaf_family_lookup_pairs4(int32_t d0) {
 #define X(DV) \
   case DV:    \
     return leaf_family_p1<T, DV, 2, 4, MODE>;
-    BN_SMALL_DIMS(X)
+    BN_PARENT_DIMS(X)
 #undef X
   }
   return nullptr;
@@ -87,7 +87,7 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
 #define X(DV) \
   case DV:    \
     return leaf_family_for_s<T, DV, MODE>(s);
-    BN_SMALL_DIMS(X)
+    BN_PARENT_DIMS(X)
 #undef X
   }
   return nullptr;

@@ -34,6 +34,19 @@ def _wide_tree(gen):
     return spec, observed, None, False
 
 
+def _wide_tree_of(classes):
+    """Q(classes) with 40 (classes,2) leaves and 20 (classes,3) leaves; every fourth leaf unobserved."""
+    def case(gen):
+        spec = [("Q", (classes,), [])]
+        for i in range(40):
+            spec.append((f"A{i}", (classes, 2), ["Q"]))
+        for i in range(20):
+            spec.append((f"B{i}", (classes, 3), ["Q"]))
+        observed = [name for k, (name, _, parents) in enumerate(spec) if parents and k % 4 != 0]
+        return spec, observed, None, False
+    return case
+
+
 def _two_parent_loopy(gen):
     """Q(3) -> F1(2), F2(2) -> 30 leaves (2 | F1, F2), every fifth leaf unobserved; T = 6."""
     spec = [("Q", (3,), []), ("F1", (3, 2), ["Q"]), ("F2", (3, 2), ["Q"])]
@@ -81,6 +94,7 @@ CASES = {
     "many_state_tree": _many_state_tree,
     "two_wide_parents": _deep_chain_with_wide_node,
 }
+CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9)})
 CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
@@ -185,7 +199,7 @@ def test_generated_network_matches_oracle(name, dtype, n):
 
 @pytest.mark.parametrize("n", [10_000, 60_000])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents"])
+@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents", "wide_tree_7_classes"])
 def test_several_fused_groups_at_large_batches(name, dtype, n):
     """Plans with more than one fused leaf-family group share the partial-sum slots of the
     log-likelihood reduction; at these batch sizes one group alone could fill all of them.  The
@@ -261,3 +275,28 @@ def test_two_parent_shapes_run_on_the_fused_kernel(shape, dtype):
         enable_profiling(False)
     label = f"leaf_family[{d0}x{d1}x{s},K=28]"
     assert sum(r["launches"] for r in report if r["kernel"] == label) >= 1, report
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("classes", [6, 7, 8, 9])
+def test_every_parent_cardinality_up_to_ten_runs_on_the_fused_kernels(classes, dtype):
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.inference_machines.hip_spa.hip_spa_inference_machine import enable_profiling, profile_report
+
+    n = 300
+    name = f"wide_tree_{classes}_classes"
+    spec, observed_names, iterations, loops, cpts, evidence, make = _build(name, dtype, n)
+    ts, network, by_name = make("cuda", dtype)
+    observed = [by_name[o] for o in observed_names]
+    machine = HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, False), network, observed, n)
+    machine.enter_evidence(Evidence([evidence[o].to(ts.dtype).to("cuda") for o in observed_names], ts))
+    enable_profiling(True)
+    try:
+        profile_report()
+        machine.log_likelihood()
+        report = profile_report()
+    finally:
+        enable_profiling(False)
+    for label in (f"leaf_family[{classes}x2,K=40]", f"leaf_family[{classes}x3,K=20]"):
+        assert sum(r["launches"] for r in report if r["kernel"] == label) >= 1, report

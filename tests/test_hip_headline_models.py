@@ -44,7 +44,9 @@ def _leaf_model(kind, dtype, device):
     def cpt(shape):
         return _rand_cpt(gen, shape).to(ts.dtype).to(ts.device)
 
-    q = Node(cpt((10,)), name="Q")
+    # "c3a" + digits: the tree model with that many latent classes instead of 10
+    classes = int(kind[3:]) if kind[3:].isdigit() else 10
+    q = Node(cpt((classes,)), name="Q")
     builder = BayesianNetworkBuilder().add_node(q)
     ys = []
     if kind == "c3b":
@@ -55,7 +57,7 @@ def _leaf_model(kind, dtype, device):
             builder.add_node(ys[-1], parents=[f1, f2])
     else:
         for i in range(784):
-            ys.append(Node(cpt((10, 2)), name=f"Y{i}"))
+            ys.append(Node(cpt((classes, 2)), name=f"Y{i}"))
             builder.add_node(ys[-1], parents=q)
     return ts, builder.build(), ys
 
@@ -115,7 +117,7 @@ class _NoYardstick:
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9"])
 def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
@@ -181,7 +183,7 @@ def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a7", "c3a8"])
 def test_784_leaf_models_statistics_from_float_and_hard_evidence(kind, dtype):
     """An even number of observations, hard rows only: the float route ingests the caller's arrays in
     its first iteration, the uint8 route the state bytes; both must equal the oracle on the tensors
@@ -439,7 +441,8 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
 @pytest.mark.parametrize("n", [1026, 16386])
 @pytest.mark.parametrize("layout", ["slices of one buffer", "separate arrays"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layout, n):
+@pytest.mark.parametrize("kind", ["c3a", "c3a7"])
+def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(kind, dtype, layout, n):
     """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 and 16 386 distinct soft +
     hard rows (five observation tiles, where the waves of a block share a chunk of families in every
     loop launch, and 65 tiles, where only the later loop launches do; a ragged last tile; evidence
@@ -452,7 +455,7 @@ def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(dtype, layou
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
     from bayesiannetwork_amd.optimizers.em_step import FlatModel
 
-    ts, network, ys = _leaf_model("c3a", dtype, "cuda")
+    ts, network, ys = _leaf_model(kind, dtype, "cuda")
     rows = _mixed_evidence(n, len(ys), 21, ts.dtype)
     if layout == "slices of one buffer":
         tensors = list(torch.stack(rows).cuda().unbind(0))
