@@ -6,7 +6,9 @@ float64 on the same inputs.  The oracle itself is pinned to the reference by the
 checked against the oracle only.
 
 Tolerance: float64 1e-9 relative; float32 as in test_hip_parity.py (1e-5 relative + 1e-7 of the
-tensor's scale; normalisers 2e-6 + 1e-7 per input message; 4x on loopy networks).
+tensor's scale; normalisers 2e-6 + 2e-7 per input message as in test_hip_headline_models.py -- the
+root of a 60-leaf tree deviates by up to 1.3e-5 at any number of classes, tools/diag_root_c.py; 4x on
+loopy networks).
 """
 
 import numpy as np
@@ -94,7 +96,7 @@ CASES = {
     "many_state_tree": _many_state_tree,
     "two_wide_parents": _deep_chain_with_wide_node,
 }
-CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9)})
+CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 12, 16)})
 CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
@@ -183,7 +185,7 @@ def test_generated_network_matches_oracle(name, dtype, n):
     for j, node in enumerate(nodes):
         inputs = len(list(network.children_of(node))) + 1 + (node in observed_set)
         check(machine.local_log_likelihoods(node), oracle.vgroups[oracle.v_of[j][0]]["c"][oracle.v_of[j][1]],
-              f"c {node.name}", extra_atol=2e-6 + 1e-7 * inputs)
+              f"c {node.name}", extra_atol=2e-6 + 2e-7 * inputs)
     # expected counts through both routes: statistics call on a second machine, accumulate on the first
     counts = machine.split_counts(machine.expected_count_sums())
     second = HipSpaInferenceMachine(
@@ -199,7 +201,7 @@ def test_generated_network_matches_oracle(name, dtype, n):
 
 @pytest.mark.parametrize("n", [10_000, 60_000])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents", "wide_tree_7_classes"])
+@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents", "wide_tree_7_classes", "wide_tree_16_classes"])
 def test_several_fused_groups_at_large_batches(name, dtype, n):
     """Plans with more than one fused leaf-family group share the partial-sum slots of the
     log-likelihood reduction; at these batch sizes one group alone could fill all of them.  The
@@ -278,7 +280,7 @@ def test_two_parent_shapes_run_on_the_fused_kernel(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("classes", [6, 7, 8, 9])
+@pytest.mark.parametrize("classes", [6, 7, 8, 9, 12, 16])
 def test_every_parent_cardinality_up_to_ten_runs_on_the_fused_kernels(classes, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings

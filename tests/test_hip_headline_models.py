@@ -117,7 +117,7 @@ class _NoYardstick:
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9", "c3a12", "c3a16"])
 def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
@@ -183,7 +183,7 @@ def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a7", "c3a8"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a7", "c3a8", "c3a16"])
 def test_784_leaf_models_statistics_from_float_and_hard_evidence(kind, dtype):
     """An even number of observations, hard rows only: the float route ingests the caller's arrays in
     its first iteration, the uint8 route the state bytes; both must equal the oracle on the tensors
@@ -441,7 +441,7 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
 @pytest.mark.parametrize("n", [1026, 16386])
 @pytest.mark.parametrize("layout", ["slices of one buffer", "separate arrays"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3a7"])
+@pytest.mark.parametrize("kind", ["c3a", "c3a7", "c3a16"])
 def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(kind, dtype, layout, n):
     """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 and 16 386 distinct soft +
     hard rows (five observation tiles, where the waves of a block share a chunk of families in every
