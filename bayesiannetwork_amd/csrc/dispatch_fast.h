@@ -699,19 +699,28 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
   // (large batches that also store the product over the chunks: measured 22 against 27 us at 60 000
   // observations on the kernel with one observation per lane and a wave per four chunks)
   const bool states_kernel = a.prod_mode == 1 ? p.ntiles < 64 : a.prod_mode != 2;
-  if (!fresh && states_kernel && p.ntiles <= env_combine_states_max() && (int32_t)w.uncovered.size() <= kMaxUncovered) {
+  // (one wave per state: a block of 64 * S threads, so up to 16 states)
+  if (S <= 16 && !fresh && states_kernel && p.ntiles <= env_combine_states_max() &&
+      (int32_t)w.uncovered.size() <= kMaxUncovered) {
     // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
-    const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_states<T, S>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return false;
-    launch(wide_combine_states<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
+    if constexpr (S <= 16) {
+      const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
+      if (lds > 48 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_states<T, S>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+      launch(wide_combine_states<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
+    }
   } else {
     // waves per block: one per group of four chunks, none to spare while the messages are fresh
-    const int32_t nw = (fresh || a.prod_mode == 2) ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
-    launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw),
-           combine_lds_bytes<S>(nw), s, arena, a);
+    int32_t nw = (fresh || a.prod_mode == 2) ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
+    while (nw > 1 && combine_lds_bytes<S>(nw) > 128 * 1024) --nw;  // (a wave then takes more of the chunks)
+    const size_t lds = combine_lds_bytes<S>(nw);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_fast<T, S>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;
+    launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw), lds, s, arena, a);
   }
   if (!launch_ok()) return false;
   if (a.prod_mode == 1) w.products_cached = true;

@@ -117,7 +117,7 @@ class _NoYardstick:
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9", "c3a12", "c3a16"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9", "c3a12", "c3a16", "c3a20"])
 def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
@@ -441,7 +441,7 @@ def test_iterations_of_a_dense_tree_in_one_launch_per_factor_group(iterations, d
 @pytest.mark.parametrize("n", [1026, 16386])
 @pytest.mark.parametrize("layout", ["slices of one buffer", "separate arrays"])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3a7", "c3a16"])
+@pytest.mark.parametrize("kind", ["c3a", "c3a7", "c3a16", "c3a20"])
 def test_whole_step_calls_on_several_tiles_equal_the_separate_calls(kind, dtype, layout, n):
     """``em_step`` and ``em_step_statistics`` on the 784-leaf model at 1 026 and 16 386 distinct soft +
     hard rows (five observation tiles, where the waves of a block share a chunk of families in every
@@ -543,3 +543,31 @@ def test_784_leaf_model_at_iteration_counts_around_the_diameter(iterations, dtyp
     _check(queried.infer_single_nodes([nodes[0]])[0], oracle.infer_single(0), "single Q", f32)
     for j, got in enumerate(queried.split_counts(queried.expected_count_sums())):
         _check(got, want_counts[j], f"query route: counts {nodes[j].name}", f32)
+
+
+@pytest.mark.parametrize("n", [1, 100])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("kind", ["c3a12", "c3a16", "c3a20"])
+def test_many_class_784_leaf_models_at_small_batches(kind, dtype, n):
+    """Few observations make many chunks of families: the combine of a many-state parent then works
+    with its largest LDS footprint."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+
+    f32 = dtype == "float32"
+    ts, network, ys = _leaf_model(kind, dtype, "cuda")
+    evidence = _mixed_evidence(n, len(ys), 13, ts.dtype)
+    oracle = _oracle_for(kind, network, ys, dtype, n, None, False, evidence)
+    settings = SpaInferenceMachineSettings(ts, False)
+    nodes = list(network.nodes)
+    want_ll = oracle.log_likelihood(False)
+    machine = HipSpaInferenceMachine(settings, network, ys, n)
+    machine.enter_evidence(Evidence([e.cuda() for e in evidence], ts))
+    for j in (0, 1, len(nodes) - 1):
+        _check(machine.infer_single_nodes([nodes[j]])[0], oracle.infer_single(j), f"single {nodes[j].name}", f32)
+    assert abs(machine.log_likelihood() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
+    one_call = HipSpaInferenceMachine(settings, network, ys, n)
+    ll, flat = one_call.em_statistics(Evidence([e.cuda() for e in evidence], ts))
+    assert abs(ll.item() - want_ll) <= (1e-5 if f32 else 1e-9) * abs(want_ll)
+    for j, got in enumerate(one_call.split_counts(flat)):
+        _check(got, oracle.infer_family(j).sum(dim=0), f"counts {nodes[j].name}", f32)
