@@ -45,16 +45,16 @@ def _flatten_cpts(cpts, device, dtype) -> torch.Tensor:
     """Concatenate CPT tensors; free when they already are consecutive views of one buffer
     (what the EM optimizers hand back), one ``torch.cat`` otherwise."""
     first = cpts[0]
-    base = getattr(first, "_base", None)
-    if base is not None and base.dim() == 1 and base.device == device and base.dtype == dtype and base.is_contiguous():
-        pos = 0
+    if first.device == device and first.dtype == dtype:
+        storage = first.untyped_storage()
+        start = pos = first.storage_offset()
         for c in cpts:
-            if getattr(c, "_base", None) is not base or c.storage_offset() != pos or not c.is_contiguous():
+            if (c.dtype != dtype or c.device != device or not c.is_contiguous() or c.storage_offset() != pos
+                    or c.untyped_storage().data_ptr() != storage.data_ptr()):
                 break
             pos += c.numel()
         else:
-            if pos == base.numel():
-                return base
+            return torch.empty(0, device=device, dtype=dtype).set_(storage, start, (pos - start,))
     return torch.cat([c.detach().to(device, dtype).reshape(-1) for c in cpts])
 
 

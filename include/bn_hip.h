@@ -317,7 +317,9 @@ int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_
  * bn_reset_messages / creation).  Written as one double to out_dev.  The reference offers no
  * stopping rule; its loops experiment watches the messages and the sum of the local
  * log-likelihoods per iteration through the callback (dev_experiments/loops/loops.py:93-120),
- * which is what this reduces to one number.
+ * which is what this reduces to one number.  The first call on a plan allocates the c_before array
+ * (hipMalloc: it synchronises the device and cannot run under stream capture); later calls only
+ * enqueue work on the stream.
  */
 int bn_normaliser_change(bn_plan* plan, double* out_dev, void* stream);
 
