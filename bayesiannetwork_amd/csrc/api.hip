@@ -781,7 +781,7 @@ int prepare_star(bn_plan* plan) {
   bool small = false;
   switch (g.dims[0]) {
 #define X(DV) case DV: small = true; break;
-    BN_SMALL_DIMS(X)
+    BN_STAR_DIMS(X)
 #undef X
   }
   if (!small) return BN_OK;
@@ -891,7 +891,7 @@ int launch_star_for_d0(bn_plan* plan, int32_t num_iterations, int32_t average, d
   case DV:    \
     return launch_star<T, DV>(plan, num_iterations, average, learning_rate, regularization, ll_out_dev, new_cpts_dev, s, \
                               from_caller);
-    BN_SMALL_DIMS(X)
+    BN_STAR_DIMS(X)
 #undef X
   }
   return 1;

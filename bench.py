@@ -74,7 +74,7 @@ def pmc_counters(kernel_label: str, model: str = "c3a"):
     return out[0], out[1]
 
 
-def build_model(ts, model: str, num_pixels: int = 784):
+def build_model(ts, model: str, num_pixels: int = 784, classes: int = 10):
     from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
 
     gen = torch.Generator().manual_seed(0)
@@ -84,7 +84,7 @@ def build_model(ts, model: str, num_pixels: int = 784):
         p = (p / p.sum(dim=-1, keepdim=True)).to(ts.dtype)
         return (p / p.sum(dim=-1, keepdim=True)).to(ts.device)
 
-    q = Node(torch.full((10,), 0.1, dtype=ts.dtype, device=ts.device), name="Q")
+    q = Node(torch.full((classes,), 1.0 / classes, dtype=ts.dtype, device=ts.device), name="Q")
     builder = BayesianNetworkBuilder().add_node(q)
     ys = []
     if model == "c3b":
@@ -97,7 +97,7 @@ def build_model(ts, model: str, num_pixels: int = 784):
             ys.append(y)
     else:
         for i in range(num_pixels):
-            y = Node(rand_cpt((10, 2)), name=f"Y{i}")
+            y = Node(rand_cpt((classes, 2)), name=f"Y{i}")
             builder.add_node(y, parents=q)
             ys.append(y)
     return builder.build(), ys

@@ -609,7 +609,8 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
 @pytest.mark.parametrize("hard", [False, True])
 @pytest.mark.parametrize("n", [1, 64, 100, 129, 1000, 1024])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-def test_one_launch_star_step_agrees_with_one_launch_per_pass(dtype, n, hard):
+@pytest.mark.parametrize("classes", [10, 7])
+def test_one_launch_star_step_agrees_with_one_launch_per_pass(classes, dtype, n, hard):
     """The cooperative one-launch EM step of the 784-leaf model against the launch-per-pass route
     (itself checked against the oracle above): log-likelihoods and parameters after each of four
     steps, to rounding."""
@@ -624,7 +625,7 @@ def test_one_launch_star_step_agrees_with_one_launch_per_pass(dtype, n, hard):
     settings = SpaInferenceMachineSettings(ts, True)
 
     def run(star):
-        network, ys = bench.build_model(ts, "c3a")
+        network, ys = bench.build_model(ts, "c3a", classes=classes)
         batches = [bench.synthetic_evidence(ts, n, len(ys), 11 + b, device) for b in range(2)]
         if hard:
             batches = [HardEvidence(torch.stack([d.argmax(dim=1) for d in b.data]), [2] * len(ys), ts,

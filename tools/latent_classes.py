@@ -1,7 +1,7 @@
 """EM step of Q(classes) -> 784 x Y(2 | Q) at 60 000 resident observations for several numbers of
-latent classes.  Up to ten classes the wide-parent / leaf-family kernels serve the model, beyond
-that the unfused kernels do:
-    python tools/latent_classes.py 5 8 10 12
+latent classes.  The wide-parent / leaf-family kernels serve the class counts they are instantiated
+for (the row says so: "fused"), the unfused kernels any other:
+    python tools/latent_classes.py 5 8 10 12 [--n 100]
 """
 import json
 import os
@@ -61,5 +61,13 @@ def run(classes, n=60000, leaves=784, steps=20):
 
 
 if __name__ == "__main__":
-    for arg in sys.argv[1:] or ["5", "8", "10", "12"]:
-        print(json.dumps(run(int(arg))), flush=True)
+    args = sys.argv[1:]
+    n = 60000
+    if "--n" in args:  # observations per step (small ones show the one-launch step of star networks)
+        at = args.index("--n")
+        n = int(args[at + 1])
+        del args[at:at + 2]
+    for arg in args or ["5", "8", "10", "12"]:
+        row = run(int(arg), n=n, steps=200 if n <= 2000 else 20)
+        row["batch"] = n
+        print(json.dumps(row), flush=True)
