@@ -64,6 +64,7 @@ struct bn_plan {
   bool graphs_off = false;                  // set for the duration of a call that must not allocate
   bool graphs_wanted = step_graphs_default();  // bn_plan_enable_step_graphs
   int64_t graph_launches = 0;
+  int64_t star_launches = 0;  // EM steps that ran as one persistent launch
 };
 
 namespace {
@@ -1180,6 +1181,8 @@ int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled) {
 
 int64_t bn_plan_step_graph_launches(const bn_plan* plan) { return plan ? plan->graph_launches : -1; }
 
+int64_t bn_plan_star_step_launches(const bn_plan* plan) { return plan ? plan->star_launches : -1; }
+
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   plan->star_wanted = enabled != 0;
@@ -1668,6 +1671,7 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
                                                             ll_out_dev, new_cpts_dev, s, from_caller);
       if (launched < 0) return launched;
       if (launched == BN_OK) {
+        ++plan->star_launches;
         // new parameters, every stored message stale: as after bn_set_cpts + bn_reset_messages
         bn::cpts_changed_fast(p);
         return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);

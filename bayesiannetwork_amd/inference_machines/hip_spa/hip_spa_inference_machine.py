@@ -678,6 +678,11 @@ class HipSpaInferenceMachine(IInferenceMachine):
         the engine launch kernel by kernel (same results)."""
         _native.check(self._lib.bn_plan_enable_step_graphs(self._plan, 1 if enabled else 0))
 
+    @property
+    def star_step_launches(self) -> int:
+        """How many ``em_step`` calls of this machine ran as one cooperative launch."""
+        return self._lib.bn_plan_star_step_launches(self._plan)
+
     def enable_star_step(self, enabled: bool = True) -> None:
         """``em_step`` on a small batch of a star network (one root, two-state leaves) is one
         cooperative launch; ``False`` makes the engine take one launch per pass (results agree to

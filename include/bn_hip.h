@@ -124,9 +124,11 @@ int64_t bn_plan_step_graph_launches(const bn_plan* plan);
  * blocks could not meet (a GPU shared with other work) yields a NaN log-likelihood, after which
  * the next bn_em_step on the plan returns BN_ERR_HIP and the plan launches per pass from then on.
  * On by default; bn_plan_enable_star_step(plan, 0) switches a plan back to one launch per pass
- * (BN_STAR_STEP=0 in the environment: the whole process).
+ * (BN_STAR_STEP=0 in the environment: the whole process); bn_plan_star_step_launches counts the
+ * steps a plan has run this way.
  */
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled);
+int64_t bn_plan_star_step_launches(const bn_plan* plan);
 
 /*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).

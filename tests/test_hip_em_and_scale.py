@@ -636,8 +636,11 @@ def test_one_launch_star_step_agrees_with_one_launch_per_pass(classes, dtype, n,
         for step in range(4):
             machine = HipSpaInferenceMachine(settings, network, ys, n)
             machine.enable_star_step(star)
+            before = machine.star_step_launches  # (per plan, and machines of one network share plans)
             ll, new = machine.em_step(batches[step % 2], 0.3, 0.01)
             trace.append((ll.clone(), new.clone()))
+            # the route under test is the one taken
+            assert machine.star_step_launches - before == (1 if star else 0)
             model.assign(new)
             if step == 2:
                 # asked after its step, the machine answers for the batch's evidence under the new parameters
