@@ -49,6 +49,20 @@ def _wide_tree_of(classes):
     return case
 
 
+def _wide_parent_of_inner_nodes(classes):
+    """Q(classes) -> 30 hidden H_i(3 | Q) -> one observed leaf Y_i(2 | H_i) each: the many-input node's
+    children are not leaf families, so its variable pass runs on the standalone wide-node kernels
+    (float32) or the generic one (float64)."""
+    def case(gen):
+        spec = [("Q", (classes,), [])]
+        for i in range(30):
+            spec.append((f"H{i}", (classes, 3), ["Q"]))
+        for i in range(30):
+            spec.append((f"Y{i}", (3, 2), [f"H{i}"]))
+        return spec, [f"Y{i}" for i in range(30) if i % 6 != 0], None, False
+    return case
+
+
 def _two_parent_loopy(gen):
     """Q(3) -> F1(2), F2(2) -> 30 leaves (2 | F1, F2), every fifth leaf unobserved; T = 6."""
     spec = [("Q", (3,), []), ("F1", (3, 2), ["Q"]), ("F2", (3, 2), ["Q"])]
@@ -97,6 +111,7 @@ CASES = {
     "two_wide_parents": _deep_chain_with_wide_node,
 }
 CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 12, 16, 20)})
+CASES.update({f"wide_parent_{classes}_of_inner_nodes": _wide_parent_of_inner_nodes(classes) for classes in (7, 10, 16, 20)})
 CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
