@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256) em_p2_fast(const T* __restrict__ arena, c
 
 #define BN_SMALL_DIMS(X) X(2) X(3) X(4) X(5) X(10)
 // cardinalities of a wide parent (the D0 of the leaf-family kernels, the S of the wide-node kernels)
-#define BN_PARENT_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(16) X(20)
+#define BN_PARENT_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(15) X(16) X(20)
 // root cardinalities of the one-launch EM step of small star networks (kernels_star.h)
 #define BN_STAR_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 // (D0, D1, S) of the leaf families with two wide parents that have a fused kernel (CPT [D0][D1][S])

@@ -110,8 +110,8 @@ CASES = {
     "many_state_tree": _many_state_tree,
     "two_wide_parents": _deep_chain_with_wide_node,
 }
-CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 12, 16, 20)})
-CASES.update({f"wide_parent_{classes}_of_inner_nodes": _wide_parent_of_inner_nodes(classes) for classes in (7, 10, 16, 20)})
+CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 12, 15, 16, 20)})
+CASES.update({f"wide_parent_{classes}_of_inner_nodes": _wide_parent_of_inner_nodes(classes) for classes in (7, 10, 15, 16, 20)})
 CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
@@ -295,7 +295,7 @@ def test_two_parent_shapes_run_on_the_fused_kernel(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("classes", [6, 7, 8, 9, 12, 16, 20])
+@pytest.mark.parametrize("classes", [6, 7, 8, 9, 12, 15, 16, 20])
 def test_every_parent_cardinality_up_to_ten_runs_on_the_fused_kernels(classes, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings

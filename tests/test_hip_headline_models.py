@@ -117,7 +117,7 @@ class _NoYardstick:
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9", "c3a12", "c3a16", "c3a20"])
+@pytest.mark.parametrize("kind", ["c3a", "c3b", "c3a6", "c3a7", "c3a8", "c3a9", "c3a12", "c3a15", "c3a16", "c3a20"])
 def test_784_leaf_models_on_distinct_rows_across_tiles(kind, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
@@ -547,7 +547,7 @@ def test_784_leaf_model_at_iteration_counts_around_the_diameter(iterations, dtyp
 
 @pytest.mark.parametrize("n", [1, 100])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("kind", ["c3a12", "c3a16", "c3a20"])
+@pytest.mark.parametrize("kind", ["c3a12", "c3a15", "c3a16", "c3a20"])
 def test_many_class_784_leaf_models_at_small_batches(kind, dtype, n):
     """Few observations make many chunks of families: the combine of a many-state parent then works
     with its largest LDS footprint."""
