@@ -4,8 +4,8 @@ ARCH  ?= gfx950
 SRC   := bayesiannetwork_amd/csrc
 OUT   := bayesiannetwork_amd/libbn_hip.so
 OBJ   := build
-HDRS  := $(wildcard $(SRC)/*.h) include/bn_hip.h
-FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude
+# -MMD: every object depends on exactly the headers it includes (build/*.d)
+FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude -MMD -MP
 OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/sampler.o $(OBJ)/plan.o
 
 all: $(OUT)
@@ -13,11 +13,11 @@ all: $(OUT)
 $(OUT): $(OBJS)
 	$(HIPCC) -fPIC --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
 
-$(OBJ)/%.o: $(SRC)/%.hip $(HDRS)
+$(OBJ)/%.o: $(SRC)/%.hip
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c -o $@ $<
 
-$(OBJ)/%.o: $(SRC)/%.cpp $(HDRS)
+$(OBJ)/%.o: $(SRC)/%.cpp
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c -o $@ $<
 
@@ -26,6 +26,8 @@ demo: examples/c_abi_demo
 
 examples/c_abi_demo: examples/c_abi_demo.cpp $(OUT) include/bn_hip.h
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< -L$(dir $(OUT)) -lbn_hip -Wl,-rpath,'$$ORIGIN/../$(dir $(OUT))'
+
+-include $(OBJS:.o=.d)
 
 clean:
 	rm -rf $(OUT) $(OBJ) examples/c_abi_demo

@@ -65,6 +65,7 @@ struct bn_plan {
   bool graphs_wanted = step_graphs_default();  // bn_plan_enable_step_graphs
   int64_t graph_launches = 0;
   int64_t star_launches = 0;  // EM steps that ran as one persistent launch
+  int64_t star_failures = 0;  // ... of which so many were found void (their blocks could not synchronise)
 };
 
 namespace {
@@ -336,9 +337,18 @@ int place_lazy_region(bn::Plan& p) {
   return BN_OK;
 }
 
+// Set for the duration of a call that must not allocate (bn_em_statistics_static): backing the lazy
+// region is then an error instead of an allocation.
+thread_local bool t_no_mapping = false;
+const char* const kNoMappingMessage =
+    "the plan's message arrays have no memory yet and this call would have to allocate it: call "
+    "bn_plan_map_message_arrays (or bn_iterate / any query) once beforehand, or bn_reset_messages "
+    "if the plan continues from an earlier statistics call";
+
 // Backs the lazy region with memory (first call that reads or writes message arrays).
 int ensure_message_arrays(bn::Plan& p) {
   if (p.lazy_elems <= 0 || p.lazy_mapped) return BN_OK;
+  if (t_no_mapping) return fail(BN_ERR_STATE, kNoMappingMessage);
   hipMemAllocationProp prop = lazy_memory_prop(p.device);
   BN_HIP_CHECK(hipMemCreate(&p.lazy_handle, p.lazy_bytes, &prop, 0));
   hipError_t err = hipMemMap(p.lazy_base, p.lazy_bytes, 0, p.lazy_handle, 0);
@@ -864,10 +874,10 @@ int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double l
                      (size_t)NW * 64 * sizeof(double) + (size_t)D0 * V * 64 * 12 +
                      (size_t)st.chunk_len * D0 * 2 * sizeof(T);
   const void* kernel = reinterpret_cast<const void*>(&bn::star_em_step<T, D0>);
-  static bool lds_allowed = false;  // per instantiation
-  if (lds > 48 * 1024 && !lds_allowed) {
+  static size_t lds_allowed[kMaxDevices] = {};  // per instantiation and device: the attribute is the device's
+  if (lds > 48 * 1024 && (p.device < 0 || p.device >= kMaxDevices || lds_allowed[p.device] < lds)) {
     BN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_allowed = true;
+    if (p.device >= 0 && p.device < kMaxDevices) lds_allowed[p.device] = lds;
   }
   void* args[] = {&a};
   const uint32_t blocks = (uint32_t)(st.chunks * st.nslices);
@@ -1173,6 +1183,12 @@ int64_t bn_plan_unmapped_bytes(const bn_plan* plan) {
   return plan->p.lazy_elems > 0 && !plan->p.lazy_mapped ? (int64_t)plan->p.lazy_bytes : 0;
 }
 
+int bn_plan_map_message_arrays(bn_plan* plan) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  if (int rc = on_plan_device(plan->p)) return rc;
+  return ensure_message_arrays(plan->p);
+}
+
 int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
   plan->graphs_wanted = enabled != 0;
@@ -1182,6 +1198,13 @@ int bn_plan_enable_step_graphs(bn_plan* plan, int32_t enabled) {
 int64_t bn_plan_step_graph_launches(const bn_plan* plan) { return plan ? plan->graph_launches : -1; }
 
 int64_t bn_plan_star_step_launches(const bn_plan* plan) { return plan ? plan->star_launches : -1; }
+
+int64_t bn_plan_star_step_failures(const bn_plan* plan) {
+  if (!plan) return -1;
+  return plan->star_failures + (plan->star.error && *plan->star.error != 0 ? 1 : 0);
+}
+
+int32_t bn_star_barrier_verdict(uint32_t seen, uint32_t target) { return bn::star_verdict(seen, target); }
 
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
@@ -1514,6 +1537,27 @@ int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t avera
                                     std::to_string(kStaticScratchElems - kLlBlocks) + " (use bn_em_statistics)");
   double* base = nullptr;
   if (int rc = static_scratch(&base)) return rc;
+  // Never back the lazy message arrays from here.  Whether the call would need them is known before
+  // anything is launched: it continues from stored messages or has a reduced iteration to complete,
+  // or one of its launches touches an array of the lazy region (a group that no fused kernel serves).
+  if (p.lazy_unmapped()) {
+    bool needed = bn::any_pending_fast(p) || !p.fresh;
+    const int32_t reduce_last = accum_dev ? 1 : 2;
+    for (size_t gi = 0; gi < p.vgroups.size() && !needed; ++gi)
+      needed = bn::variable_needs_arrays(p, gi, 1) || (num_iterations > 1 && bn::variable_needs_arrays(p, gi, 0));
+    for (size_t fi = 0; fi < p.fgroups.size() && !needed; ++fi) {
+      needed = bn::factor_needs_arrays(p, fi, 1, 1, num_iterations == 1 ? 1 : 0, reduce_last) ||
+               (num_iterations > 1 && bn::factor_needs_arrays(p, fi, 0, 0, 1, reduce_last)) ||
+               (num_iterations > 2 && bn::factor_needs_arrays(p, fi, 0, 0, 0, reduce_last)) ||
+               (accum_dev && !bn::is_fused_family_group(p, fi) && bn::factor_needs_arrays(p, fi, 0, 1, 1, 0));
+    }
+    if (needed) return fail(BN_ERR_STATE, std::string("bn_em_statistics_static: ") + kNoMappingMessage);
+  }
+  struct NoMapping {
+    bool before;
+    ~NoMapping() { t_no_mapping = before; }
+  } no_mapping{t_no_mapping};
+  t_no_mapping = true;  // (a backstop: the check above has covered every launch of the call)
   // the same kernels as bn_em_statistics, with their partial sums in the static array
   struct Swap {
     bn::Plan& p;
@@ -1644,9 +1688,12 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   if (star_steps_enabled() && plan->star_wanted && num_iterations >= 2 && !g_profiling.load(std::memory_order_relaxed) && !plan->graphs_off) {
     if (int rc = prepare_star(plan)) return rc;
     if (plan->star.ok && *plan->star.error != 0) {
+      // An earlier one-launch step could not synchronise its blocks (the GPU was shared with other
+      // work).  That step changed nothing (kernels_star.h: parameters as before, NaN log-likelihood);
+      // it is counted, and the plan launches per pass from now on.
       plan->star.ok = false;
-      return fail(BN_ERR_HIP, "an earlier one-launch EM step could not synchronise its blocks (the GPU was shared "
-                              "with other work); its results are void, this plan launches per pass from now on");
+      ++plan->star_failures;
+      *plan->star.error = 0;
     }
     if (plan->star.ok) {
       // float evidence in 16-byte aligned arrays is read where it lies (the plan's copy would be

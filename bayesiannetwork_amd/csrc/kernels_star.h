@@ -19,8 +19,9 @@
 // The grid must be co-resident: it is kept to half the chip's CUs (kStarMaxBlocks; launched through
 // hipLaunchCooperativeKernel, which checks residency, if BN_STAR_COOPERATIVE is set: that launch
 // measured 21 us slower per step).  The barrier's spin is bounded, so a launch that cannot make
-// progress ends with a host-visible error flag and a NaN log-likelihood instead of hanging; the
-// next bn_em_step call on the plan reports it and goes back to one launch per pass.
+// progress ends instead of hanging: all blocks then agree that the step is void (star_give_up), the
+// parameters stay as they were, the log-likelihood is NaN and a host-visible flag is set; the next
+// bn_em_step call on the plan counts the failure and goes back to one launch per pass.
 #pragma once
 
 #include "kernels_leaf.h"
@@ -82,26 +83,49 @@ __device__ __forceinline__ U shared_load(const U* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// All blocks of a counter arrive, then all leave.  Every wave first waits for its own coherent
-// stores to have been performed; thread 0 then counts the block in and waits for the epoch's total.
-// The bounded wait makes every wave reach the end of the kernel whatever happens.
+// A counter that has been given up on carries this on top of its arrivals.  Epochs advance by at most
+// a few thousand per launch, so a distance of half of it from the target cannot be mistaken.
+constexpr uint32_t kStarPoison = 0x40000000u;
+constexpr int32_t kStarWait = 0, kStarPass = 1, kStarAbort = 2;
+
+// What a block that waits for `target` arrivals makes of the counter's value.
+__host__ __device__ constexpr int32_t star_verdict(uint32_t seen, uint32_t target) {
+  const int32_t ahead = (int32_t)(seen - target);
+  return ahead >= (int32_t)(kStarPoison / 2) ? kStarAbort : (ahead >= 0 ? kStarPass : kStarWait);
+}
+
+// Gives the counter up, unless all blocks have arrived meanwhile: a compare-and-swap, so that in the
+// one order all blocks see either the target was reached first (everybody passes, this block too) or
+// the poison came first (everybody who looks afterwards aborts, nobody has passed before).
+__device__ __forceinline__ int32_t star_give_up(uint32_t* counter, uint32_t target) {
+  uint32_t seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const int32_t verdict = star_verdict(seen, target);
+    if (verdict != kStarWait) return verdict;
+    if (__hip_atomic_compare_exchange_strong(counter, &seen, seen + kStarPoison, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
+      return kStarAbort;
+  }
+}
+
+// All blocks of a counter arrive, then all leave - or all learn that the launch is given up.  Every
+// wave first waits for its own coherent stores to have been performed; thread 0 then counts the
+// block in and waits for the epoch's total.  The bounded wait makes every wave reach the end of the
+// kernel whatever happens; the verdict is the same for every block of the counter.
 __device__ __forceinline__ bool star_barrier(uint32_t* counter, uint32_t target, int32_t* error) {
   __shared__ int32_t ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int32_t good = 0;
-    for (int32_t spin = 0; spin < (1 << 22); ++spin) {
-      const uint32_t seen = shared_load(counter);
-      if ((int32_t)(seen - target) >= 0) {
-        good = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
+    int32_t verdict = kStarWait;
+    for (int32_t spin = 0; spin < (1 << 22) && verdict == kStarWait; ++spin) {
+      verdict = star_verdict(shared_load(counter), target);
+      if (verdict == kStarWait) __builtin_amdgcn_s_sleep(2);
     }
-    if (!good) shared_store(error, 1);
-    ok = good;
+    if (verdict == kStarWait) verdict = star_give_up(counter, target);
+    if (verdict == kStarAbort) shared_store(error, 1);
+    ok = verdict == kStarPass;
   }
   __syncthreads();
   return ok != 0;
@@ -416,6 +440,9 @@ __global__ void __launch_bounds__(64 * kStarWaves) star_em_step(StarArgs<T> a) {
     }
     slice_epoch += (uint32_t)a.C;
     alive = star_barrier(slice_counter, slice_epoch, a.error);
+    // a block that leaves the iterations will never arrive at the grid-wide barrier: it gives that
+    // one up as well, so that the other slices' blocks do not wait for it
+    if (!alive && threadIdx.x == 0) (void)star_give_up(a.barrier, a.epoch0 + (uint32_t)nblocks);
   }
 
   // ---- iteration T on the fly: log-likelihood and count sums
@@ -519,7 +546,17 @@ __global__ void __launch_bounds__(64 * kStarWaves) star_em_step(StarArgs<T> a) {
     alive = star_barrier(a.barrier, a.epoch0 + (uint32_t)nblocks, a.error);
   }
   if (!alive) {
-    // a barrier ran out of patience: no result (the caller sees a NaN log-likelihood)
+    // A barrier was given up (the same verdict in every block): no result.  The step leaves the
+    // parameters as they were - the plan's snapshot untouched, the caller's buffer filled with them -
+    // and the caller sees a NaN log-likelihood and the error flag.
+    if (sl != 0) return;
+    if (a.new_cpts) {
+      for (int32_t i = threadIdx.x; i < (fb1 - fb0) * E; i += 64 * NW) {
+        const int64_t off = a.cpt_off[fb0 + i / E] + i % E;
+        a.new_cpts[off] = a.cpts[off];
+      }
+      if (blockIdx.x == 0 && threadIdx.x < D0) a.new_cpts[a.root_cpt_off + threadIdx.x] = a.cpts[a.root_cpt_off + threadIdx.x];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.ll_out = __builtin_nan("");
     return;
   }

@@ -162,11 +162,17 @@ int upload(const std::vector<U>& host, U** dev) {
 
 // Walk order for a request: every requested node and its ancestors, parents first (depth-first,
 // iterative), in the order the reference's recursion visits them (samplers/torch_sampler.py:43-52).
-int build_tables(bn_sampler* s, const int32_t* nodes, int32_t count) {
-  std::vector<int32_t> request(nodes, nodes + count);
-  if (s->d_out_pos && request == s->request) return BN_OK;
-  free_tables(s);
-  std::vector<int32_t> position(s->n_nodes, -1), walk;
+// Host only.  position[j] = place of node j in `walk`, -1 for nodes the request does not need.
+int walk_order(const std::vector<std::vector<int32_t>>& parents, const std::vector<int32_t>& request,
+               std::vector<int32_t>& position, std::vector<int32_t>& walk) {
+  const size_t n_nodes = parents.size();
+  position.assign(n_nodes, -1);
+  walk.clear();
+  // A node is unvisited, open (its parents have been pushed and it waits below them) or positioned.
+  // The open nodes of the stack are a chain in which each is a parent of the one below it, so
+  // meeting an open node among the parents of the node on top is exactly a cycle; a dense graph
+  // may push an unvisited node many times, which is not one.
+  std::vector<char> open(n_nodes, 0);
   for (int32_t j : request) {
     std::vector<int32_t> stack{j};
     while (!stack.empty()) {
@@ -176,20 +182,31 @@ int build_tables(bn_sampler* s, const int32_t* nodes, int32_t count) {
         continue;
       }
       bool ready = true;
-      for (int32_t q : s->parents[cur])
-        if (position[q] < 0) {
-          stack.push_back(q);
-          ready = false;
-        }
+      for (int32_t q : parents[cur]) {
+        if (position[q] >= 0) continue;
+        if (open[q] || open[cur]) return fail(BN_ERR_INVALID, "the parent relation has a cycle");
+        stack.push_back(q);
+        ready = false;
+      }
       if (!ready) {
-        if ((int64_t)stack.size() > 4 * (int64_t)s->n_nodes + 4) return fail(BN_ERR_INVALID, "the parent relation has a cycle");
+        open[cur] = 1;
         continue;
       }
       stack.pop_back();
+      open[cur] = 0;
       position[cur] = (int32_t)walk.size();
       walk.push_back(cur);
     }
   }
+  return BN_OK;
+}
+
+int build_tables(bn_sampler* s, const int32_t* nodes, int32_t count) {
+  std::vector<int32_t> request(nodes, nodes + count);
+  if (s->d_out_pos && request == s->request) return BN_OK;
+  free_tables(s);
+  std::vector<int32_t> position, walk;
+  if (int rc = walk_order(s->parents, request, position, walk)) return rc;
   std::vector<int32_t> w_states, w_poff{0}, w_parents, out_pos;
   std::vector<int64_t> w_cpt;
   for (int32_t j : walk) {
@@ -266,6 +283,29 @@ int bn_sampler_destroy(bn_sampler* sampler) {
 }
 
 int64_t bn_sampler_cpt_elements(const bn_sampler* sampler) { return sampler ? sampler->cpt_total : -1; }
+
+int32_t bn_sampler_walk_order(int32_t num_nodes, const int32_t* parent_offsets, const int32_t* parent_indices,
+                              const int32_t* nodes, int32_t num_requested, int32_t* order_out) {
+  if (num_nodes < 1 || !parent_offsets || num_requested < 0 || (num_requested > 0 && !nodes) || !order_out)
+    return fail(BN_ERR_INVALID, "bad argument");
+  if (parent_offsets[0] != 0 || (parent_offsets[num_nodes] > 0 && !parent_indices))
+    return fail(BN_ERR_INVALID, "bad parent offsets");
+  std::vector<std::vector<int32_t>> parents(num_nodes);
+  for (int32_t j = 0; j < num_nodes; ++j) {
+    if (parent_offsets[j + 1] < parent_offsets[j]) return fail(BN_ERR_INVALID, "bad parent offsets");
+    for (int32_t q = parent_offsets[j]; q < parent_offsets[j + 1]; ++q) {
+      if (parent_indices[q] < 0 || parent_indices[q] >= num_nodes || parent_indices[q] == j)
+        return fail(BN_ERR_INVALID, "parent index out of range");
+      parents[j].push_back(parent_indices[q]);
+    }
+  }
+  std::vector<int32_t> request(nodes, nodes + num_requested), position, walk;
+  for (int32_t j : request)
+    if (j < 0 || j >= num_nodes) return fail(BN_ERR_INVALID, "requested node out of range");
+  if (int rc = walk_order(parents, request, position, walk)) return rc;
+  std::copy(walk.begin(), walk.end(), order_out);
+  return (int32_t)walk.size();
+}
 
 int64_t bn_sampler_workspace_bytes(bn_sampler* sampler, const int32_t* nodes, int32_t num_requested, int64_t num_samples) {
   if (!sampler || num_requested < 0 || num_samples < 0 || (num_requested > 0 && !nodes)) return -1;

@@ -47,6 +47,8 @@ def _declare(lib):
     lib.bn_plan_device_bytes.argtypes = [c_void_p]
     lib.bn_plan_unmapped_bytes.restype = c_int64
     lib.bn_plan_unmapped_bytes.argtypes = [c_void_p]
+    lib.bn_plan_map_message_arrays.restype = c_int
+    lib.bn_plan_map_message_arrays.argtypes = [c_void_p]
     lib.bn_em_step.restype = c_int
     lib.bn_em_step.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_double, c_int32, c_int32, c_double, c_double,
                                c_void_p, c_void_p, c_void_p]
@@ -59,6 +61,10 @@ def _declare(lib):
     lib.bn_plan_enable_star_step.argtypes = [c_void_p, c_int32]
     lib.bn_plan_star_step_launches.restype = c_int64
     lib.bn_plan_star_step_launches.argtypes = [c_void_p]
+    lib.bn_plan_star_step_failures.restype = c_int64
+    lib.bn_plan_star_step_failures.argtypes = [c_void_p]
+    lib.bn_star_barrier_verdict.restype = c_int32
+    lib.bn_star_barrier_verdict.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.bn_plan_step_graph_launches.restype = c_int64
     lib.bn_plan_step_graph_launches.argtypes = [c_void_p]
     lib.bn_set_cpts.restype = c_int
@@ -116,6 +122,8 @@ def _declare(lib):
     lib.bn_sampler_cpt_elements.argtypes = [c_void_p]
     lib.bn_sampler_workspace_bytes.restype = c_int64
     lib.bn_sampler_workspace_bytes.argtypes = [c_void_p, i32p, c_int32, c_int64]
+    lib.bn_sampler_walk_order.restype = c_int32
+    lib.bn_sampler_walk_order.argtypes = [c_int32, i32p, i32p, i32p, c_int32, i32p]
     lib.bn_sampler_sample.restype = c_int
     lib.bn_sampler_sample.argtypes = [c_void_p, c_void_p, i32p, c_int32, c_int64, c_uint64, c_void_p, c_void_p, c_void_p]
     lib.bn_profile_enable.restype = c_int
@@ -130,14 +138,14 @@ def _declare(lib):
 
 EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
-    "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_plan_unmapped_bytes", "bn_plan_enable_step_graphs",
-    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_star_step_launches", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
+    "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_plan_unmapped_bytes", "bn_plan_map_message_arrays", "bn_plan_enable_step_graphs",
+    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_star_step_launches", "bn_plan_star_step_failures", "bn_star_barrier_verdict", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_static", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
     "bn_exact_log_likelihood", "bn_exact_marginal",
     "bn_sampler_create", "bn_sampler_destroy", "bn_sampler_cpt_elements", "bn_sampler_workspace_bytes",
-    "bn_sampler_sample",
+    "bn_sampler_walk_order", "bn_sampler_sample",
     "bn_profile_enable", "bn_profile_report", "bn_profile_only", "bn_profile_stride",
 )
 

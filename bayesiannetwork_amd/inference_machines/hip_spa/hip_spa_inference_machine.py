@@ -112,6 +112,7 @@ class _PlanHandle:
         # the tensor's version counter at that time), set by ``em_step``
         self.snapshot_of = None
         self.last_stream = None  # (raw handle, torch stream) of the plan's latest call
+        self.star_failures_reported = 0  # one-launch EM steps found void that a warning has been given for
 
     def __del__(self):
         if self.handle:
@@ -542,7 +543,28 @@ class HipSpaInferenceMachine(IInferenceMachine):
         self._evidence_to_restore = evidence
         self.must_iterate = True
         self.iterations_run = self._num_iterations
+        self.report_void_steps()  # (of earlier calls: this one may still be running)
         return ll, new
+
+    def report_void_steps(self, synchronize: bool = False) -> int:
+        """One-launch EM steps of this machine's plan that were found void so far (their blocks could
+        not meet at a barrier because the GPU was shared with other work).  Such a step changes
+        nothing: the parameters it returns are the old ones, its log-likelihood is NaN, and the
+        engine launches per pass from then on.  A ``RuntimeWarning`` is given once per failure.
+        ``synchronize=True`` waits for the plan's stream first, which makes the answer include the
+        step that was submitted last."""
+        if synchronize:
+            torch.cuda.current_stream(self._device).synchronize()
+        failures = int(self._lib.bn_plan_star_step_failures(self._plan))
+        if failures > self._owner.star_failures_reported:
+            import warnings
+
+            warnings.warn(
+                f"{failures - self._owner.star_failures_reported} one-launch EM step(s) could not synchronise their "
+                "blocks (GPU shared with other work) and were skipped: parameters unchanged, log-likelihood NaN; "
+                "the plan launches one kernel per pass from now on", RuntimeWarning, stacklevel=2)
+            self._owner.star_failures_reported = failures
+        return failures
 
     def em_step_statistics(self, evidence: Evidence, out: Optional[torch.Tensor] = None):
         """The statistics half of ``em_step`` for runs that add them up over several devices before the

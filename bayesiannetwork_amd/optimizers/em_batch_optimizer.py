@@ -39,6 +39,7 @@ class EmBatchOptimizer(IBatchOptimizer):
     def optimize(self, evidence_loader: EvidenceLoader) -> None:
         cfg = self._settings
         flat_model = None
+        stepped = False  # some step ran as one engine call (em_step)
         for epoch in range(cfg.num_epochs):
             pending = []
             for iteration, evidence in enumerate(evidence_loader):
@@ -50,9 +51,11 @@ class EmBatchOptimizer(IBatchOptimizer):
                     if flat_model is None:
                         flat_model = FlatModel.of(self._network)
                         flat_model.assign(flat_model.gather())  # nodes read one shared buffer from here on
+                        machine = None  # back to the pool first: the rebuilt machine gets the same plan
                         machine = self._factory(self._network)
                     ll, flat = machine.em_step(evidence, cfg.learning_rate, cfg.regularization)
                     flat_model.assign(flat)
+                    stepped = True
                     # back to the pool before the next machine is built: that one then gets this very
                     # plan, which already holds the new parameters
                     machine = None
@@ -119,3 +122,9 @@ class EmBatchOptimizer(IBatchOptimizer):
             if self._logger:
                 for iteration, ll in pending:
                     self._logger.log(epoch, iteration, float(ll))
+        if stepped:
+            # a one-launch step that could not run is a skipped step: say so before returning (the
+            # pooled plan of the last step comes back with this machine)
+            machine = self._factory(self._network)
+            if hasattr(machine, "report_void_steps"):
+                machine.report_void_steps(synchronize=True)

@@ -99,6 +99,14 @@ int64_t bn_plan_device_bytes(const bn_plan* plan);
 int64_t bn_plan_unmapped_bytes(const bn_plan* plan);
 
 /*
+ * Back those arrays with memory now (what the first call that needs them would do by itself), for
+ * callers that set a plan up where they may allocate and use it where they may not
+ * (bn_em_statistics_static).  No effect when they are backed already.  No counterpart in the
+ * reference, whose buffers all exist from construction (spa_v3/factor_graph.py:48-60, :197-213).
+ */
+int bn_plan_map_message_arrays(bn_plan* plan);
+
+/*
  * Small batches are bound by the chain of dependent kernel launches of a call (the reference's own
  * batch size is 100, dev_experiments/mnist/mnist.py:38).  On request, bn_em_statistics* and
  * bn_em_step run their launch sequence as one captured graph from the third call on that finds the
@@ -121,14 +129,23 @@ int64_t bn_plan_step_graph_launches(const bn_plan* plan);
  * dependent dispatches).  Same iterations, same formulas; sums are taken in another order, so
  * results agree with the launch-per-pass route to rounding (2e-6 relative in float32), not bit for
  * bit.  The barriers need all blocks on the GPU at once; their wait is bounded, and a step whose
- * blocks could not meet (a GPU shared with other work) yields a NaN log-likelihood, after which
- * the next bn_em_step on the plan returns BN_ERR_HIP and the plan launches per pass from then on.
+ * blocks could not meet (a GPU shared with other work) is void as a whole: all blocks agree on it
+ * before any parameter is touched, the plan's CPT snapshot stays as it was, new_cpts_dev receives
+ * those unchanged parameters and *ll_out_dev a NaN.  The next bn_em_step on the plan notices, counts
+ * the failure and launches per pass from then on.  bn_plan_star_step_failures returns that count
+ * plus a failure not yet noticed; it reads a flag the kernel writes, so it is exact once the stream
+ * has run the step (after a synchronisation), and a caller that must not lose a step checks it then.
  * On by default; bn_plan_enable_star_step(plan, 0) switches a plan back to one launch per pass
  * (BN_STAR_STEP=0 in the environment: the whole process); bn_plan_star_step_launches counts the
  * steps a plan has run this way.
  */
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled);
 int64_t bn_plan_star_step_launches(const bn_plan* plan);
+int64_t bn_plan_star_step_failures(const bn_plan* plan);
+/* The decision rule of that kernel's barrier, for tests: 0 = keep waiting, 1 = all blocks have
+ * arrived, 2 = the launch was given up; `seen` is the arrival counter's value, `target` the value
+ * that means "all arrived".  Host-only, needs no GPU. */
+int32_t bn_star_barrier_verdict(uint32_t seen, uint32_t target);
 
 /*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
@@ -231,6 +248,11 @@ int bn_em_statistics(bn_plan* plan, int32_t num_iterations, int32_t average, dou
  * the message state still lives in the plan, which bn_plan_create allocated.  Fails with
  * BN_ERR_INVALID when 1024 + bn_plan_cpt_elements(plan) exceeds the array.  Every call on a GPU
  * shares that GPU's array: calls that overlap on one GPU (different streams or threads) race.
+ * A plan may still hold message arrays without memory (bn_plan_unmapped_bytes > 0).  A call on a
+ * freshly reset plan whose observed families all run on the fused kernels never touches them; any
+ * other call would have to back them, which this entry point refuses: it returns BN_ERR_STATE
+ * before launching anything (a second call without bn_reset_messages in between, a plan with
+ * groups on the unfused kernels).  bn_plan_map_message_arrays at set-up time removes the condition.
  */
 int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t average, double* ll_out_dev,
                             double* accum_dev, void* stream);
@@ -403,6 +425,14 @@ int bn_sampler_create(int dtype, int32_t num_nodes, const int32_t* num_states, c
 int bn_sampler_destroy(bn_sampler* sampler);
 /* Element count of the flat CPT buffer the sampler reads (all CPTs in node order). */
 int64_t bn_sampler_cpt_elements(const bn_sampler* sampler);
+/*
+ * The order in which a request's nodes and their ancestors are drawn (parents before children, the
+ * reference's recursion order, samplers/torch_sampler.py:43-52): node ids to order_out (room for
+ * num_nodes entries), their number as the return value; BN_ERR_INVALID when the parent relation has
+ * a cycle or an index is out of range.  Host-only: needs no sampler object and no GPU.
+ */
+int32_t bn_sampler_walk_order(int32_t num_nodes, const int32_t* parent_offsets, const int32_t* parent_indices,
+                              const int32_t* nodes, int32_t num_requested, int32_t* order_out);
 /* Bytes of device workspace bn_sampler_sample needs for this request (drawn states of the requested
  * nodes and their ancestors, int32 [nodes walked][num_samples]); -1 on a bad argument. */
 int64_t bn_sampler_workspace_bytes(bn_sampler* sampler, const int32_t* nodes, int32_t num_requested, int64_t num_samples);

@@ -224,3 +224,22 @@ def test_flat_cpt_buffer_is_recognised_without_a_copy():
     assert gap.data_ptr() != buf.data_ptr() and torch.equal(gap, torch.cat([buf[0:4], buf[6:8]]))
     assert _flatten_cpts([buf[0:4]], cpu, torch.float64).dtype == torch.float64
     assert _flatten_cpts([torch.ones(2, 2), torch.zeros(3)], cpu, torch.float32).shape == (7,)
+
+
+def test_barrier_verdict_of_the_one_launch_step():
+    """The decision every block of the one-launch EM step takes from an arrival counter's value:
+    wait below the target, pass at or above it, give up when the counter carries the poison a block
+    adds when its wait runs out - also when the 32-bit epochs wrap around."""
+    lib = _native.load()
+    wait, go, void = 0, 1, 2
+    poison = 0x40000000
+    for target in (128, 5_000, 0xFFFFFF00, 0xFFFFFFFF, 17):
+        for behind in (1, 2, 127, 4096):
+            assert lib.bn_star_barrier_verdict((target - behind) & 0xFFFFFFFF, target) == wait
+        for ahead in (0, 1, 127, 100_000):
+            assert lib.bn_star_barrier_verdict((target + ahead) & 0xFFFFFFFF, target) == go
+        # poisoned before everybody arrived, with any number of arrivals around it
+        for arrived in (-128, -1, 0, 1, 128):
+            assert lib.bn_star_barrier_verdict((target + arrived + poison) & 0xFFFFFFFF, target) == void
+    # a poisoned counter stays void for the epochs of later launches too (they abort at once)
+    assert lib.bn_star_barrier_verdict((1000 + poison) & 0xFFFFFFFF, 1000 + 16 * 128) == void

@@ -56,3 +56,46 @@ def test_sampler_is_reproducible_and_handles_the_empty_request():
     for j, node in enumerate(nodes):
         assert int(a[:, j].min()) >= 0 and int(a[:, j].max()) < node.num_states
     assert BatchedBayesianNetworkSampler(network, ts).sample(7, []).shape == (7, 0)
+
+
+def _walk_order(parents, request):
+    """bn_sampler_walk_order (host-only C ABI): the draw order of a request, or a BnError."""
+    from bayesiannetwork_amd.inference_machines.hip_spa import _native
+
+    lib = _native.load()
+    offsets, indices = [0], []
+    for ps in parents:
+        indices.extend(ps)
+        offsets.append(len(indices))
+    out = _native.i32_array([0] * len(parents))
+    count = lib.bn_sampler_walk_order(len(parents), _native.i32_array(offsets), _native.i32_array(indices),
+                                      _native.i32_array(request), len(request), out)
+    if count < 0:
+        raise _native.BnError(lib.bn_last_error().decode())
+    return list(out[:count])
+
+
+def test_walk_order_of_dense_graphs_and_cycles():
+    import pytest
+    from bayesiannetwork_amd.inference_machines.hip_spa import _native
+
+    # a fully connected 12-node DAG (node j has every earlier node as a parent, listed latest first, so the
+    # depth-first walk pushes unvisited nodes again and again): 1 + 12 * 11 / 2 stack entries, no cycle
+    n = 12
+    parents = [list(range(j - 1, -1, -1)) for j in range(n)]
+    order = _walk_order(parents, [n - 1])
+    assert sorted(order) == list(range(n))
+    place = {node: i for i, node in enumerate(order)}
+    assert all(place[q] < place[j] for j in range(n) for q in parents[j])
+    # a 30-node chain in which every node has its five predecessors as parents
+    parents = [list(range(max(0, j - 5), j)) for j in range(30)]
+    order = _walk_order(parents, [29, 3])
+    place = {node: i for i, node in enumerate(order)}
+    assert len(order) == 30 and all(place[q] < place[j] for j in range(30) for q in parents[j])
+    # only the requested nodes' ancestors are walked
+    assert _walk_order([[], [0], [0], [1]], [3]) == [0, 1, 3]
+    # a true two-cycle, and a longer one reached through an acyclic prefix
+    with pytest.raises(_native.BnError, match="cycle"):
+        _walk_order([[1], [0]], [0])
+    with pytest.raises(_native.BnError, match="cycle"):
+        _walk_order([[], [0, 3], [1], [2]], [2])

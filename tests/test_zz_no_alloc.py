@@ -59,14 +59,21 @@ def _evidence(ts, observed, n, seed):
     return Evidence(data, ts)
 
 
-def _statistics(entry, machine):
+def _statistics(entry, machine, expect=0):
     ll = torch.full((1,), float("nan"), device="cuda", dtype=torch.float64)
     counts = torch.full((machine._lib.bn_plan_cpt_elements(machine._plan),), float("nan"), device="cuda",
                         dtype=torch.float64)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    unmapped_before = machine.unmapped_bytes
     rc = entry(machine._plan, machine.num_iterations, 0, ctypes.c_void_p(ll.data_ptr()),
                ctypes.c_void_p(counts.data_ptr()), machine._stream())
-    assert rc == 0, machine._lib.bn_last_error().decode()
+    assert rc == expect, machine._lib.bn_last_error().decode()
     torch.cuda.synchronize()
+    if entry is machine._lib.bn_em_statistics_static:
+        # the call neither took nor returned device memory, whatever it answered
+        assert torch.cuda.mem_get_info()[0] == free_before
+        assert machine.unmapped_bytes == unmapped_before
     return ll.item(), counts.cpu().numpy()
 
 
@@ -106,6 +113,65 @@ def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
     last.reset_messages()
     _statistics(lib.bn_em_statistics_static, last)
     assert torch.cuda.mem_get_info()[0] == free_before
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_static_scratch_entry_point_never_backs_the_lazy_message_arrays(dtype):
+    """A plan whose observed families all run on the fused kernels keeps its message arrays without
+    memory through any number of statistics calls on reset messages; a call that would need them (a
+    second one without a reset: it has a reduced iteration to complete) is refused before anything is
+    launched, and served once the caller has backed the arrays."""
+    from bayesiannetwork_amd.bayesian_network import BayesianNetworkBuilder, Node
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.inference_machines.hip_spa import _native
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    lib = _native.load()
+    ts = TorchSettings(device="cuda", dtype=dtype)
+    gen = torch.Generator().manual_seed(3)
+
+    def cpt(shape):
+        p = torch.rand(shape, generator=gen, dtype=torch.float64) + 0.05
+        return (p / p.sum(-1, keepdim=True)).to(ts.dtype).to(ts.device)
+
+    q = Node(cpt((10,)), name="Q")
+    builder = BayesianNetworkBuilder().add_node(q)
+    leaves = []
+    for i in range(784):
+        leaf = Node(cpt((10, 2)), name=f"Y{i}")
+        builder.add_node(leaf, parents=q)
+        leaves.append(leaf)
+    network = builder.build()
+    settings = SpaInferenceMachineSettings(ts, False)
+    n = 700
+    evidence = _evidence(ts, leaves, n, 9)
+    static_machine = HipSpaInferenceMachine(settings, network, leaves, n)
+    plain_machine = HipSpaInferenceMachine(settings, network, leaves, n)
+    for machine in (static_machine, plain_machine):
+        machine.enter_evidence(evidence)
+    lazy = static_machine.unmapped_bytes
+    assert lazy > 0
+    ll_s, counts_s = _statistics(lib.bn_em_statistics_static, static_machine)
+    ll_p, counts_p = _statistics(lib.bn_em_statistics, plain_machine)
+    assert abs(ll_s - ll_p) <= 1e-12 * abs(ll_p)
+    np.testing.assert_allclose(counts_s, counts_p, rtol=1e-11, atol=1e-13 * float(np.abs(counts_p).max()))
+    assert static_machine.unmapped_bytes == lazy
+    # a second call without a reset would have to complete the reduced iteration into the arrays
+    _statistics(lib.bn_em_statistics_static, static_machine, expect=-3)
+    assert "bn_reset_messages" in lib.bn_last_error().decode()
+    assert static_machine.unmapped_bytes == lazy
+    # after a reset the plan is as new: served again, still nothing backed
+    static_machine.reset_messages()
+    ll_again, counts_again = _statistics(lib.bn_em_statistics_static, static_machine)
+    assert ll_again == ll_s and np.array_equal(counts_again, counts_s)
+    assert static_machine.unmapped_bytes == lazy
+    # with the arrays backed by the caller, calls that continue from stored messages are served too
+    assert lib.bn_plan_map_message_arrays(static_machine._plan) == 0
+    assert static_machine.unmapped_bytes == 0
+    ll_2, counts_2 = _statistics(lib.bn_em_statistics_static, static_machine)
+    ll_2p, counts_2p = _statistics(lib.bn_em_statistics, plain_machine)
+    assert abs(ll_2 - ll_2p) <= 1e-12 * abs(ll_2p)
+    np.testing.assert_allclose(counts_2, counts_2p, rtol=1e-11, atol=1e-13 * float(np.abs(counts_2p).max()))
 
 
 def test_static_scratch_entry_point_rejects_networks_beyond_its_scratch():
