@@ -130,7 +130,9 @@ constexpr int64_t kLdsLimit = 158 * 1024;
 struct ProfRecord {
   std::string label;
   double alg_bytes;
-  std::vector<hipEvent_t> events;  // start, stop, start, stop, ...
+  double alg_flops;
+  std::vector<hipEvent_t> events;      // start, stop, start, stop, ...
+  std::vector<const void*> kernels;    // the kernel of each pair
 };
 std::mutex g_prof_mutex;
 std::vector<ProfRecord> g_prof;
@@ -151,7 +153,7 @@ bool take_event(hipEvent_t* ev) {
   return hipEventCreate(ev) == hipSuccess;
 }
 
-bool next_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+bool next_launch_events(const void* kernel, hipEvent_t* start, hipEvent_t* stop) {
   std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (!g_region_open || g_prof.empty()) return false;
   if (!take_event(start)) return false;
@@ -161,10 +163,13 @@ bool next_launch_events(hipEvent_t* start, hipEvent_t* stop) {
   }
   g_prof.back().events.push_back(*start);
   g_prof.back().events.push_back(*stop);
+  g_prof.back().kernels.push_back(kernel);
   return true;
 }
 
-void prof_begin(const std::string& label, double alg_bytes, hipStream_t) {
+// alg_flops: the additions, multiplications and divisions of the launch's message updates as the
+// formulas state them (0 = not counted for this kind of launch).
+void prof_begin(const std::string& label, double alg_bytes, hipStream_t, double alg_flops = 0.0) {
   if (!g_profiling.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (!g_prof_prefix.empty() && label.compare(0, g_prof_prefix.size(), g_prof_prefix) != 0) return;
@@ -172,6 +177,7 @@ void prof_begin(const std::string& label, double alg_bytes, hipStream_t) {
   ProfRecord r;
   r.label = label;
   r.alg_bytes = alg_bytes;
+  r.alg_flops = alg_flops;
   g_prof.push_back(std::move(r));
   g_region_open = true;
 }
@@ -186,7 +192,7 @@ double variable_bytes(const bn::Plan& p, const bn::VariableGroup& g) {
   double per_obs = 0;
   for (size_t k = 0; k < g.nodes.size(); ++k) {
     int32_t live_out = 0;
-    for (int32_t i = 0; i < g.num_inputs; ++i) live_out += g.out_off[k * g.num_inputs + i] >= 0;
+    for (int32_t i = 0; i < g.num_inputs; ++i) live_out += g.out_off[k * g.num_inputs + i] != bn::kNoArray;
     per_obs += (double)g.num_states * g.num_inputs + (double)g.num_states * live_out + 1;
   }
   return per_obs * (double)p.N * (double)p.elem_size;
@@ -505,7 +511,8 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
         const bn::TreeGroupTables& tables = bn::fast_state(p)->tree.at((int32_t)fi);
         const bool exact = it == tree_count;
         prof_begin(flabel(exact ? "tree_iteration_exact" : "tree_iteration", g),
-                   (tables.bytes_per_observation + (exact ? tables.exact_bytes_per_observation : 0.0)) * (double)p.npad, s);
+                   (tables.bytes_per_observation + (exact ? tables.exact_bytes_per_observation : 0.0)) * (double)p.npad, s,
+                   4.0 * g.dims[0] * g.dims[1] * (double)g.nodes.size() * (double)p.N);
         if (!bn::launch_tree_iteration(p, fi, (it - 1) & 1, exact, s))
           return fail(BN_ERR_HIP, "launch of factor_tree_mfma failed");
         prof_end(s);
@@ -547,8 +554,10 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
       {
         std::string label = flabel("factor_pass", g);
         double bytes = factor_bytes(p, g, false);
-        bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes);
-        prof_begin(label, bytes, s);
+        double flops = 0;
+        bn::factor_profile(p, (size_t)(&g - p.fgroups.data()), label, bytes, &flops,
+                           reduce_last == 1 && it == iterations - 1);
+        prof_begin(label, bytes, s, flops);
       }
       if (p.lazy_unmapped() && bn::factor_needs_arrays(p, (size_t)(&g - p.fgroups.data()), fresh, it == 0 ? 1 : 0,
                                                        it == iterations - 1 ? 1 : 0, reduce_last))
@@ -1867,8 +1876,9 @@ int bn_profile_report(char* buffer, int64_t capacity) {
     records.swap(g_prof);
   }
   std::vector<std::string> labels;
-  std::vector<double> total_ms, alg_bytes;
+  std::vector<double> total_ms, alg_bytes, alg_flops;
   std::vector<int64_t> launches;
+  std::vector<std::vector<const void*>> label_kernels;
   for (auto& r : records) {
     double region_ms = 0.0;
     bool ok = !r.events.empty();
@@ -1888,19 +1898,40 @@ int bn_profile_report(char* buffer, int64_t capacity) {
         total_ms.push_back(0.0);
         launches.push_back(0);
         alg_bytes.push_back(r.alg_bytes);
+        alg_flops.push_back(r.alg_flops);
+        label_kernels.emplace_back();
       }
       total_ms[i] += region_ms;
       launches[i] += 1;
+      for (const void* k : r.kernels)
+        if (std::find(label_kernels[i].begin(), label_kernels[i].end(), k) == label_kernels[i].end())
+          label_kernels[i].push_back(k);
     }
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (hipEvent_t e : r.events) g_event_pool.push_back(e);
   }
   std::string json = "[";
   for (size_t i = 0; i < labels.size(); ++i) {
-    char num[160];
-    std::snprintf(num, sizeof(num), "\", \"launches\": %lld, \"total_ms\": %.6f, \"alg_bytes\": %.1f}",
-                  (long long)launches[i], total_ms[i], alg_bytes[i]);
-    json += std::string(i ? ", " : "") + "{\"kernel\": \"" + labels[i] + num;
+    // what the compiler made of the label's kernels: registers, static LDS and spill space of each
+    // distinct instantiation, sorted - it changes whenever the generated code does
+    std::vector<std::string> sigs;
+    for (const void* k : label_kernels[i]) {
+      hipFuncAttributes attr;
+      if (hipFuncGetAttributes(&attr, k) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      char one[96];
+      std::snprintf(one, sizeof(one), "v%d.l%zu.s%zu", attr.numRegs, (size_t)attr.sharedSizeBytes, (size_t)attr.localSizeBytes);
+      sigs.push_back(one);
+    }
+    std::sort(sigs.begin(), sigs.end());
+    std::string signature;
+    for (const auto& one : sigs) signature += (signature.empty() ? "" : "|") + one;
+    char num[200];
+    std::snprintf(num, sizeof(num), "\", \"launches\": %lld, \"total_ms\": %.6f, \"alg_bytes\": %.1f, \"alg_flops\": %.1f, ",
+                  (long long)launches[i], total_ms[i], alg_bytes[i], alg_flops[i]);
+    json += std::string(i ? ", " : "") + "{\"kernel\": \"" + labels[i] + num + "\"signature\": \"" + signature + "\"}";
   }
   json += "]";
   if ((int64_t)json.size() + 1 > capacity) json = "[]";

@@ -756,26 +756,44 @@ inline bool variable_profile(const Plan& p, size_t gi, std::string& label, doubl
   }
   if (!st->vgroup_wide[gi]) return false;
   bool any_fused = false;
-  double fused_bytes = 0;
-  for (int32_t j : g.nodes) {
-    const WideNode& w = st->wide[st->wide_of_node[j]];
-    if (w.fused_fgroup < 0) continue;
-    any_fused = true;
-    // inputs + outputs of the covered slots are moved by the leaf-family kernel
-    fused_bytes += 2.0 * w.S * (double)w.covered.size() * (double)p.N * (double)p.elem_size;
-  }
+  for (int32_t j : g.nodes) any_fused = any_fused || st->wide[st->wide_of_node[j]].fused_fgroup >= 0;
   if (!any_fused) return false;
   label = "wide_combine[I=" + std::to_string(g.num_inputs) + ",S=" + std::to_string(g.num_states) + "]";
-  bytes -= fused_bytes;
+  // what is left of the variable pass once the covered slots are the leaf-family kernel's: the other
+  // slots' messages in and out, and the normaliser
+  bytes = 0;
+  for (int32_t j : g.nodes) {
+    const WideNode& w = st->wide[st->wide_of_node[j]];
+    const bool fused = w.fused_fgroup >= 0;
+    double live_out = 0;
+    for (int32_t slot = 0; slot < w.I; ++slot) {
+      if (fused && std::find(w.covered.begin(), w.covered.end(), slot) != w.covered.end()) continue;
+      live_out += g.out_off[(size_t)w.vpos * g.num_inputs + slot] != kNoArray;
+    }
+    const double slots_in = fused ? (double)w.uncovered.size() : (double)w.I;
+    bytes += ((double)w.S * (slots_in + live_out) + 1.0) * (double)p.N * (double)p.elem_size;
+  }
   return true;
 }
 
-inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double& bytes) {
+// flops: the additions, multiplications and divisions of one flooding iteration of the group's
+// families as the message formulas state them (with_counts: plus the expected-count products of
+// the last iteration of a statistics call); written only for fused one-parent groups
+inline bool factor_profile(const Plan& p, size_t fi, std::string& label, double& bytes, double* flops = nullptr,
+                           bool with_counts = false) {
   FastState* st = fast_state(p);
   if (!st) return false;
   auto it = st->fused.find((int32_t)fi);
   if (it == st->fused.end()) return false;
   const FactorGroup& g = p.fgroups[fi];
+  if (flops && it->second.wide_index2 < 0) {
+    // per family and observation: message to the parent D0 (2S - 1); the parent's leave-one-out
+    // message, normalised, D0 divisions + D0 additions + D0 multiplications; message to the leaf
+    // S (2 D0 - 1); the leaf's normaliser and its message back 3 S; counts 3 D0 S
+    const double d0 = g.dims[0], sv = g.dims[1];
+    const double per = d0 * (2 * sv - 1) + 3 * d0 + sv * (2 * d0 - 1) + 3 * sv + (with_counts ? 3 * d0 * sv : 0.0);
+    *flops = per * (double)g.nodes.size() * (double)p.N;
+  }
   const WideNode& w = st->wide[it->second.wide_index];
   // the factor pass itself + the covered part of the wide parent's variable pass + the leaf
   // variables' whole variable pass (inputs observation + factor message, outputs message + c)

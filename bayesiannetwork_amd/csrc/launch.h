@@ -11,8 +11,9 @@
 
 namespace bn {
 
-// Hands out the event pair for the next launch of the open region; false = launch untimed.
-using LaunchEventSource = bool (*)(hipEvent_t* start, hipEvent_t* stop);
+// Hands out the event pair for the next launch of the open region (and takes note of the kernel that
+// is launched); false = launch untimed.
+using LaunchEventSource = bool (*)(const void* kernel, hipEvent_t* start, hipEvent_t* stop);
 
 inline LaunchEventSource& launch_event_source() {
   static LaunchEventSource source = nullptr;
@@ -41,7 +42,7 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
   void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {const_cast<void*>(static_cast<const void*>(&args))...};
   hipEvent_t start = nullptr, stop = nullptr;
   LaunchEventSource source = launch_event_source();
-  if (source && source(&start, &stop)) {
+  if (source && source(reinterpret_cast<const void*>(kernel), &start, &stop)) {
     (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, stream, start, stop, 0);
   } else {
     (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, stream);

@@ -25,6 +25,21 @@ import torch
 from ..bayesian_network import BayesianNetwork
 
 
+def all_reduce_sum(buffer: torch.Tensor) -> None:
+    """In-place SUM over the ranks of torch.distributed: the one collective of a data-parallel EM step.
+    On RCCL (backend "nccl") the device buffer goes into the collective as it is.  gloo reduces in
+    host memory: a device buffer is taken there and back explicitly, in this thread and on the current
+    stream, rather than by gloo's own staging threads (which were seen to stall after a few dozen
+    steps when two ranks share one GPU, the set-up in which gloo stands in for RCCL)."""
+    dist = torch.distributed
+    if buffer.is_cuda and dist.get_backend() == "gloo":
+        host = buffer.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buffer.copy_(host)
+    else:
+        dist.all_reduce(buffer, op=dist.ReduceOp.SUM)
+
+
 def expected_counts(machine, network: BayesianNetwork, sharded: bool = False,
                     ll: Optional[float] = None) -> Tuple[List[torch.Tensor], Optional[float]]:
     """Returns (per-node mean family marginals in network order, log-likelihood).
@@ -42,7 +57,7 @@ def expected_counts(machine, network: BayesianNetwork, sharded: bool = False,
             ll_sum = (ll * n_local) if (ll is not None and avg) else (ll if ll is not None else 0.0)
             tail = torch.tensor([ll_sum, n_local], dtype=torch.float64, device=flat.device)
             packed = torch.cat([flat, tail])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            all_reduce_sum(packed)
             flat, ll_total, n_total = packed[:-2], packed[-2].item(), packed[-1].item()
             if ll is not None:
                 ll = ll_total / n_total if avg else ll_total
@@ -60,7 +75,7 @@ def expected_counts(machine, network: BayesianNetwork, sharded: bool = False,
         avg = machine.settings.average_log_likelihood
         ll_sum = (ll * n_local) if (ll is not None and avg) else (ll if ll is not None else 0.0)
         packed = torch.cat([flat, torch.tensor([ll_sum, n_local], dtype=torch.float64, device=flat.device)])
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        all_reduce_sum(packed)
         n_total = packed[-1].item()
         if ll is not None:
             ll = packed[-2].item() / n_total if avg else packed[-2].item()
@@ -196,7 +211,7 @@ def reduce_statistics(machine, flat_sums: torch.Tensor, ll, sharded: bool):
     else:
         packed[total : total + 1].fill_((ll * n_local) if avg else ll)
     packed[total + 1 :].fill_(n_local)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    all_reduce_sum(packed)
     n_total = packed[total + 1]
     ll_out = packed[total] / n_total if avg else packed[total]
     if not isinstance(ll, torch.Tensor):
@@ -219,7 +234,7 @@ def reduce_packed(machine, packed: torch.Tensor, sharded: bool):
     if avg:
         packed[total : total + 1].mul_(n_local)
     packed[total + 1 :].fill_(n_local)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    all_reduce_sum(packed)
     ll = packed[total : total + 1] / packed[total + 1] if avg else packed[total : total + 1]
     return packed[:total], ll, packed[total + 1]
 

@@ -59,7 +59,7 @@ def _evidence(ts, observed, n, seed):
     return Evidence(data, ts)
 
 
-def _statistics(entry, machine, expect=0):
+def _statistics(entry, machine, expect=0, warm=False):
     ll = torch.full((1,), float("nan"), device="cuda", dtype=torch.float64)
     counts = torch.full((machine._lib.bn_plan_cpt_elements(machine._plan),), float("nan"), device="cuda",
                         dtype=torch.float64)
@@ -71,9 +71,12 @@ def _statistics(entry, machine, expect=0):
     assert rc == expect, machine._lib.bn_last_error().decode()
     torch.cuda.synchronize()
     if entry is machine._lib.bn_em_statistics_static:
-        # the call neither took nor returned device memory, whatever it answered
-        assert torch.cuda.mem_get_info()[0] == free_before
+        # the call backed no message array, whatever it answered; and once the HIP runtime has loaded
+        # the kernels involved (their first launch in a process takes device memory of the runtime's
+        # own), it neither takes nor returns device memory
         assert machine.unmapped_bytes == unmapped_before
+        if warm:
+            assert torch.cuda.mem_get_info()[0] == free_before
     return ll.item(), counts.cpu().numpy()
 
 
@@ -95,6 +98,19 @@ def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
         for entry in (lib.bn_em_statistics_static, lib.bn_em_statistics):
             machine = HipSpaInferenceMachine(settings, network, observed, n)
             machine.enter_evidence(evidence)
+            if entry is lib.bn_em_statistics_static and machine.unmapped_bytes > 0:
+                # This network has nodes on the unfused kernels, whose launches touch message arrays that
+                # may have no memory yet.  The static entry point then refuses before launching anything
+                # (BN_ERR_STATE) instead of backing them; set-up code backs them once.
+                ll_probe = torch.zeros((1,), device="cuda", dtype=torch.float64)
+                rc = entry(machine._plan, machine.num_iterations, 0, ctypes.c_void_p(ll_probe.data_ptr()), None,
+                           machine._stream())
+                if rc != 0:
+                    assert rc == -3 and "bn_plan_map_message_arrays" in lib.bn_last_error().decode()
+                    assert lib.bn_plan_map_message_arrays(machine._plan) == 0
+                    assert machine.unmapped_bytes == 0
+                else:
+                    machine.reset_messages()
             pair.append((machine,) + _statistics(entry, machine))
         (static_machine, ll_s, counts_s), (plain_machine, ll_p, counts_p) = pair
         assert np.isfinite(ll_s) and np.isfinite(counts_s).all()
@@ -111,7 +127,7 @@ def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     last.reset_messages()
-    _statistics(lib.bn_em_statistics_static, last)
+    _statistics(lib.bn_em_statistics_static, last, warm=True)
     assert torch.cuda.mem_get_info()[0] == free_before
 
 
@@ -157,12 +173,12 @@ def test_static_scratch_entry_point_never_backs_the_lazy_message_arrays(dtype):
     np.testing.assert_allclose(counts_s, counts_p, rtol=1e-11, atol=1e-13 * float(np.abs(counts_p).max()))
     assert static_machine.unmapped_bytes == lazy
     # a second call without a reset would have to complete the reduced iteration into the arrays
-    _statistics(lib.bn_em_statistics_static, static_machine, expect=-3)
+    _statistics(lib.bn_em_statistics_static, static_machine, expect=-3, warm=True)
     assert "bn_reset_messages" in lib.bn_last_error().decode()
     assert static_machine.unmapped_bytes == lazy
     # after a reset the plan is as new: served again, still nothing backed
     static_machine.reset_messages()
-    ll_again, counts_again = _statistics(lib.bn_em_statistics_static, static_machine)
+    ll_again, counts_again = _statistics(lib.bn_em_statistics_static, static_machine, warm=True)
     assert ll_again == ll_s and np.array_equal(counts_again, counts_s)
     assert static_machine.unmapped_bytes == lazy
     # with the arrays backed by the caller, calls that continue from stored messages are served too

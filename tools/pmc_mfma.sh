@@ -5,9 +5,10 @@ set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_mfma
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --model c5 --batch 32768 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/run.log 2>&1 || { echo "pass failed"; tail -5 $OUT/run.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --model c5 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $OUT/run.log 2>&1 || { echo "pass failed"; tail -5 $OUT/run.log; exit 1; }
 python3 - <<PY
 import csv, glob, json, re
 from collections import defaultdict

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Issue-side picture of the kernels of one EM step: one rocprofv3 --pmc pass with seven SQ counters
-# and GRBM_GUI_ACTIVE.  Run on the GPU box from the repo root:  bash tools/pmc_valu.sh [bench args]
+# and GRBM_GUI_ACTIVE.  Run on the GPU box from the repo root:  [PMC_TAG=_c3b] bash tools/pmc_valu.sh [bench args]
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc_valu
+TAG=${PMC_TAG:-}
+OUT=$R/gpurun_out/pmc_valu$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing "$@" > $OUT/run.log 2>&1 || { echo "pass failed"; tail -5 $OUT/run.log; exit 1; }
@@ -31,5 +33,5 @@ for k, c in acc.items():
     m["wait_share_of_wave_cycles"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else None
     out[k] = m
     print(k[:60], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in m.items()})
-json.dump(out, open("$R/gpurun_out/pmc_valu.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/pmc_valu$TAG.json", "w"), indent=1)
 PY
