@@ -364,7 +364,9 @@ def launch_ranks(n_ranks: int) -> int:
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # the contract is one JSON line on stdout; anything else a library printed there goes to stderr
+    for text in out.decode().splitlines():
+        print(text, file=sys.stdout if text.startswith("{") else sys.stderr)
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 
