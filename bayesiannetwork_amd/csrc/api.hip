@@ -15,6 +15,7 @@
 
 #include "dispatch_fast.h"
 #include "kernels_star.h"
+#include "kernels_finish.h"
 #include "error.h"
 #include "launch.h"
 #include "kernels_generic.h"
@@ -66,6 +67,8 @@ struct bn_plan {
   int64_t graph_launches = 0;
   int64_t star_launches = 0;  // EM steps that ran as one persistent launch
   int64_t star_failures = 0;  // ... of which so many were found void (their blocks could not synchronise)
+  uint32_t* finish_counter = nullptr;  // arrival counter of em_finish (kernels_finish.h), zero between launches
+  int32_t finish_shape = 0;            // 0 not examined yet, 1 the plan's steps can end in em_finish, -1 they cannot
 };
 
 namespace {
@@ -522,7 +525,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
     const int32_t fresh = p.fresh ? 1 : 0;
     for (auto& g : p.vgroups) {
       const int32_t K = (int32_t)g.nodes.size();
-      {
+      if (g_profiling.load(std::memory_order_relaxed)) {  // (labels and byte counts cost host time: only when asked for)
         std::string label = vlabel(g);
         double bytes = variable_bytes(p, g);
         bn::variable_profile(p, (size_t)(&g - p.vgroups.data()), label, bytes);
@@ -551,7 +554,7 @@ int iterate_t(bn::Plan& p, int32_t iterations, int32_t reduce_last, hipStream_t 
       if (t_discard_last_messages && reduce_last && it == iterations - 1 &&
           !bn::is_fused_family_group(p, (size_t)(&g - p.fgroups.data())))
         continue;
-      {
+      if (g_profiling.load(std::memory_order_relaxed)) {
         std::string label = flabel("factor_pass", g);
         double bytes = factor_bytes(p, g, false);
         double flops = 0;
@@ -734,11 +737,18 @@ int ll_partial_launch(bn::Plan& p, hipStream_t s, int32_t* blocks_out) {
 // The launches of bn_em_statistics up to, not including, the final sum of the log-likelihood
 // partials (which writes to the caller's address): iterations with the last one in reduce mode,
 // log-likelihood partial sums into p.scratch (*ll_blocks of them), count sums into accum (if wanted).
+int statistics_sums(bn::Plan& p, double* accum, hipStream_t s, int32_t* ll_blocks);
+
 int statistics_launches(bn::Plan& p, int32_t num_iterations, int32_t reduce_last, double* accum, hipStream_t s,
                         int32_t* ll_blocks) {
   int rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, reduce_last, s)
                              : iterate_t<double>(p, num_iterations, reduce_last, s);
   if (rc != BN_OK) return rc;
+  return statistics_sums(p, accum, s, ll_blocks);
+}
+
+// The second half: log-likelihood partial sums into p.scratch, count sums into accum (if wanted).
+int statistics_sums(bn::Plan& p, double* accum, hipStream_t s, int32_t* ll_blocks) {
   // the fused families left their normalisers as per-observation partial sums
   const int used = bn::ll_partials_reduced(p, p.scratch, kLlBlocks, s);
   if (used < 0) return fail(BN_ERR_HIP, "launch of ll_partial_listed failed");
@@ -915,6 +925,98 @@ int launch_star_for_d0(bn_plan* plan, int32_t num_iterations, int32_t average, d
 #undef X
   }
   return 1;
+}
+
+// Can the plan's whole-step calls end in em_finish (kernels_finish.h)?  A star: one parentless wide
+// node, every other node a leaf of the one fused one-parent group.
+bool finish_shape_ok(bn_plan* plan) {
+  if (plan->finish_shape != 0) return plan->finish_shape > 0;
+  plan->finish_shape = -1;
+  static const bool enabled = [] {
+    const char* v = getenv("BN_STEP_FINISH");
+    return !(v && v[0] == '0');
+  }();
+  bn::Plan& p = plan->p;
+  bn::FastState* fs = bn::fast_state(p);
+  if (!enabled || !fs || fs->fused.size() != 1 || fs->wide.size() != 1) return false;
+  const auto& entry = *fs->fused.begin();
+  const bn::FactorGroup& g = p.fgroups[entry.first];
+  const bn::WideNode& w = fs->wide[entry.second.wide_index];
+  if (entry.second.wide_index2 >= 0 || g.dims.size() != 2 || (int32_t)g.nodes.size() != p.n_nodes - 1) return false;
+  if (g.dims[0] > bn::kFinishMaxStates || g.dims[1] > bn::kFinishMaxStates) return false;
+  if (!p.parents[w.node].empty()) return false;
+  const bn::FactorGroup& rg = p.fgroups[p.fgroup_of[w.node]];
+  if (rg.dims.size() != 1 || rg.nodes.size() != 1 || fs->n_unfused_entries != rg.dims[0]) return false;
+  // (the root's sums are taken in the order of the specialised count kernel: only where that one serves the root)
+  if (!bn::em_root_lookup<float>(rg.dims[0])) return false;
+  if (hipMalloc(reinterpret_cast<void**>(&plan->finish_counter), sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(plan->finish_counter, 0, sizeof(uint32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  plan->finish_shape = 1;
+  return true;
+}
+
+// The tail of a whole step as one launch: what statistics_sums + m_step_rows do.  Returns 1 when the
+// plan's state does not allow it (the caller then takes those), BN_OK when launched.
+template <typename T>
+int launch_finish(bn_plan* plan, double learning_rate, double regularization, double ll_scale, double* ll_out_dev,
+                  void* new_cpts_dev, hipStream_t s, int32_t* ll_blocks) {
+  bn::Plan& p = plan->p;
+  bn::FastState* fs = bn::fast_state(p);
+  const auto& entry = *fs->fused.begin();
+  const bn::FusedFamily& fam = entry.second;
+  if (!fam.pending || !fam.em_ready) return 1;  // the last iteration did not run in reduce mode with counts
+  const bn::FactorGroup& g = p.fgroups[entry.first];
+  const bn::WideNode& w = fs->wide[fam.wide_index];
+  const bn::FactorGroup& rg = p.fgroups[p.fgroup_of[w.node]];
+  bn::FinishArgs<T> a;
+  a.arena = static_cast<const T*>(p.arena);
+  a.c_offs = fs->d_ll_offs;
+  a.n_listed = fs->n_ll_offs;
+  a.ll_rows = fam.ll_part;
+  a.ll_row_count = fam.ll_rows;
+  a.N = p.N;
+  a.npad = p.npad;
+  // as ll_partials_reduced cuts the sum for a single fused group
+  a.ll_blocks = (int32_t)std::min<int64_t>(kLlBlocks, (a.n_listed + a.ll_row_count) * ((p.npad + 255) / 256));
+  if (a.ll_blocks <= 0) return 1;
+  a.ll_partial = p.scratch;
+  a.root_in_off = rg.in_off[0];
+  a.root_cpt_off = rg.cpt_off[0];
+  a.root_states = rg.dims[0];
+  a.ntiles = p.ntiles;
+  // as em_accumulate_t cuts the root's sum when the root is the only node that goes through the partial sums
+  int32_t nchunks = em_chunks(p, 1);
+  if (p.cpt_total > 0)
+    nchunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nchunks, (p.scratch_elems - kLlBlocks) / p.cpt_total));
+  a.root_chunks = nchunks;
+  a.root_partial = p.scratch + kLlBlocks + a.root_cpt_off * nchunks;
+  a.em_partial = static_cast<const T*>(fam.em_partial);
+  a.cpt_off = g.d_cpt;
+  a.K = (int32_t)g.nodes.size();
+  a.D0 = g.dims[0];
+  a.S = g.dims[1];
+  a.slots = fam.slots_used;
+  a.cpts = static_cast<T*>(p.cpts);
+  a.new_cpts = static_cast<T*>(new_cpts_dev);
+  a.accum = plan->accum_slot;
+  a.learning_rate = learning_rate;
+  a.regularization = regularization;
+  a.ll_scale = ll_scale;
+  a.ll_out = ll_out_dev;
+  a.arrived = plan->finish_counter;
+  const int64_t rows = (int64_t)a.K * a.D0;
+  const uint32_t blocks = (uint32_t)((a.ll_blocks + bn::kFinishLlPerBlock - 1) / bn::kFinishLlPerBlock +
+                                     (a.root_chunks + bn::kWavesPerBlock - 1) / bn::kWavesPerBlock +
+                                     (rows + bn::kWavesPerBlock - 1) / bn::kWavesPerBlock);
+  prof_begin("em_finish", 0.0, s);
+  bn::launch(bn::em_finish<T>, dim3(blocks), dim3(256), 0, s, a);
+  BN_LAUNCH_CHECK("em_finish");
+  prof_end(s);
+  *ll_blocks = a.ll_blocks;
+  return BN_OK;
 }
 
 void drop_step_graphs(bn_plan* plan) {
@@ -1169,6 +1271,7 @@ int bn_plan_destroy(bn_plan* plan) {
   release_star(plan);
   if (plan->capture_stream) (void)hipStreamDestroy(plan->capture_stream);
   if (plan->accum_slot) (void)hipFree(plan->accum_slot);
+  if (plan->finish_counter) (void)hipFree(plan->finish_counter);
   bn::release_fast(plan->p);
   release(plan->p);
   (void)hipSetDevice(prev);
@@ -1752,8 +1855,24 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   const int rc = run_sequence(
       plan, key, num_iterations, s, &from_graph, &ll_blocks, [&](hipStream_t on, bool in_graph, int32_t* blocks) {
         t_discard_last_messages = true;
-        const int rc2 = statistics_launches(p, num_iterations, 1, plan->accum_slot, on, blocks);
+        int rc2 = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 1, on) : iterate_t<double>(p, num_iterations, 1, on);
         t_discard_last_messages = false;
+        if (rc2) return rc2;
+        if (finish_shape_ok(plan)) {
+          // sums and M-step in one launch (the caller's addresses stay out of a captured graph)
+          rc2 = p.dtype == BN_F32
+                    ? launch_finish<float>(plan, learning_rate, regularization, ll_scale, in_graph ? nullptr : ll_out_dev,
+                                           in_graph ? nullptr : new_cpts_dev, on, blocks)
+                    : launch_finish<double>(plan, learning_rate, regularization, ll_scale, in_graph ? nullptr : ll_out_dev,
+                                            in_graph ? nullptr : new_cpts_dev, on, blocks);
+          if (rc2 < 0) return rc2;
+          if (rc2 == BN_OK) {
+            ll_written = !in_graph;
+            bn::cpts_changed_fast(p);
+            return p.dtype == BN_F32 ? reset_messages_t<float>(p, on) : reset_messages_t<double>(p, on);
+          }
+        }
+        rc2 = statistics_sums(p, plan->accum_slot, on, blocks);
         if (rc2) return rc2;
         // M-step on the plan's own snapshot, in place; the caller's copy is written by the same kernel
         // unless the kernel runs from a graph (the caller's address may differ from call to call)

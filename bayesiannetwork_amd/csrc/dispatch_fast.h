@@ -766,10 +766,11 @@ inline bool variable_profile(const Plan& p, size_t gi, std::string& label, doubl
     const WideNode& w = st->wide[st->wide_of_node[j]];
     const bool fused = w.fused_fgroup >= 0;
     double live_out = 0;
-    for (int32_t slot = 0; slot < w.I; ++slot) {
-      if (fused && std::find(w.covered.begin(), w.covered.end(), slot) != w.covered.end()) continue;
-      live_out += g.out_off[(size_t)w.vpos * g.num_inputs + slot] != kNoArray;
-    }
+    std::vector<char> is_covered(w.I, 0);
+    if (fused)
+      for (int32_t slot : w.covered) is_covered[slot] = 1;
+    for (int32_t slot = 0; slot < w.I; ++slot)
+      if (!is_covered[slot]) live_out += g.out_off[(size_t)w.vpos * g.num_inputs + slot] != kNoArray;
     const double slots_in = fused ? (double)w.uncovered.size() : (double)w.I;
     bytes += ((double)w.S * (slots_in + live_out) + 1.0) * (double)p.N * (double)p.elem_size;
   }
