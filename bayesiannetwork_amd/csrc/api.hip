@@ -44,6 +44,7 @@ struct StepGraph {
 // What the one-launch EM step of a star network needs (kernels_star.h); set up on first use.
 struct StarState {
   bool checked = false, ok = false;
+  bool stream = false;  // star_em_stream (evidence streamed per iteration) instead of star_em_step (kept in registers)
   int32_t fgroup = -1, root = -1, d0 = 0, chunks = 0, chunk_len = 0, nslices = 0;
   double* part_mant = nullptr;
   int32_t* part_exp = nullptr;
@@ -792,6 +793,27 @@ void release_star(bn_plan* plan) {
   st = StarState();
 }
 
+// The streaming one-launch kernel for a root of d0 states (nullptr: none), and the dynamic LDS a block
+// of it needs with chunk_len families per block (*cpt_in_lds: their CPT rows included)
+const void* stream_kernel(int dtype, int32_t d0) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return dtype == BN_F32 ? reinterpret_cast<const void*>(&bn::star_em_stream<float, DV>) \
+                           : reinterpret_cast<const void*>(&bn::star_em_stream<double, DV>);
+    BN_STAR_DIMS(X)
+#undef X
+  }
+  return nullptr;
+}
+size_t stream_lds_bytes(int32_t d0, int32_t chunk_len, size_t elem_size, size_t budget, int32_t* cpt_in_lds) {
+  constexpr size_t V = 2, NW = bn::kStarWaves;
+  const size_t base = (size_t)2 * d0 * V * 64 * 12 + NW * V * 64 * 12 + NW * 64 * sizeof(double) + (size_t)d0 * V * 64 * 12;
+  const size_t cpt_rows = (size_t)chunk_len * d0 * 2 * elem_size;
+  *cpt_in_lds = base + cpt_rows <= budget ? 1 : 0;
+  return base + (*cpt_in_lds ? cpt_rows : 0);
+}
+
 // Is the plan a star (kernels_star.h) small enough for the one-launch step?  Allocates its buffers.
 int prepare_star(bn_plan* plan) {
   StarState& st = plan->star;
@@ -816,20 +838,63 @@ int prepare_star(bn_plan* plan) {
   }
   if (!small) return BN_OK;
   const int64_t nslices = p.npad / bn::kStarSlice;
-  if (p.npad % bn::kStarSlice != 0 || nslices < 1 || nslices > bn::kStarMaxSlices) return BN_OK;
+  if (p.npad % bn::kStarSlice != 0 || nslices < 1) return BN_OK;
   // every block has to be resident at once: at most half of the device's CUs (a block fills one)
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) != hipSuccess) {
     (void)hipGetLastError();
     return BN_OK;
   }
-  const int64_t max_blocks = std::min<int64_t>(bn::kStarMaxBlocks, cus / 2);
-  if (max_blocks < nslices) return BN_OK;
-  int32_t chunks = (int32_t)std::min<int64_t>(bn::kStarChunks, max_blocks / nslices);
-  chunks = std::max(1, std::min(chunks, K));
-  const int32_t chunk_len = (K + chunks - 1) / chunks;
-  chunks = (K + chunk_len - 1) / chunk_len;
-  if ((chunk_len + bn::kStarWaves - 1) / bn::kStarWaves > bn::kStarFamilies) return BN_OK;
+  int32_t chunks = 0, chunk_len = 0;
+  {
+    const int64_t max_blocks = std::min<int64_t>(bn::kStarMaxBlocks, cus / 2);
+    if (nslices <= bn::kStarMaxSlices && max_blocks >= nslices) {
+      chunks = (int32_t)std::min<int64_t>(bn::kStarChunks, max_blocks / nslices);
+      chunks = std::max(1, std::min(chunks, K));
+      chunk_len = (K + chunks - 1) / chunks;
+      chunks = (K + chunk_len - 1) / chunk_len;
+      if ((chunk_len + bn::kStarWaves - 1) / bn::kStarWaves > bn::kStarFamilies) chunks = 0;  // too many families for the registers
+    }
+  }
+  if (chunks == 0) {
+    // Larger batches: the streaming kernel, two of whose blocks fit on a CU (every block has to be
+    // resident: twice as many blocks as the chip has CUs at most), a power of two of chunks per slice.
+    // (measured on the 784-leaf model: ahead of one launch per pass up to about 3 000 observations -
+    // 0.094 against 0.114 ms per step at 1 536, 0.099 against 0.118 at 2 048 -, level at 3 072 and
+    // behind it from there on, where a wave has a dozen and more families to walk per iteration;
+    // BN_STREAM_MAX_SLICES moves the limit, in slices of 128 observations)
+    static const int64_t max_slices = [] {
+      const char* v = getenv("BN_STREAM_MAX_SLICES");
+      return v ? (int64_t)atoi(v) : (int64_t)24;
+    }();
+    if (nslices > std::min<int64_t>(max_slices, bn::kStreamMaxSlices)) return BN_OK;
+    const void* kernel = stream_kernel(p.dtype, g.dims[0]);
+    if (!kernel) return BN_OK;
+    // the most chunks per slice whose blocks the runtime says are all resident at once
+    chunks = 0;
+    for (int32_t want = bn::kStarChunks; want >= 1 && chunks == 0; --want) {
+      if (want > K) continue;
+      const int32_t len = (K + want - 1) / want;
+      int32_t in_lds = 0, per_cu = 0;
+      // (two blocks per CU where the CPT rows leave room: 80 KiB each; otherwise one with up to 150 KiB)
+      size_t lds = stream_lds_bytes(g.dims[0], len, p.elem_size, 80 * 1024, &in_lds);
+      if (!in_lds) lds = stream_lds_bytes(g.dims[0], len, p.elem_size, 150 * 1024, &in_lds);
+      if (lds > 48 * 1024 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * bn::kStarWaves, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      if ((int64_t)want * nslices <= (int64_t)per_cu * cus) {
+        chunk_len = len;
+        chunks = (K + len - 1) / len;
+      }
+    }
+    if (chunks == 0) return BN_OK;
+    st.stream = true;
+  }
   st.fgroup = entry.first;
   st.root = w.node;
   st.d0 = g.dims[0];
@@ -843,7 +908,7 @@ int prepare_star(bn_plan* plan) {
   BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.count_part), counts * sizeof(double)));
   BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.root_part), (size_t)nslices * st.d0 * sizeof(double)));
   BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.ll_part), (size_t)(chunks * nslices + nslices) * sizeof(double)));
-  const size_t counters = (size_t)(2 + bn::kStarMaxSlices) * bn::kStarCounterStride * sizeof(uint32_t);
+  const size_t counters = (size_t)(2 + std::max<int64_t>(bn::kStarMaxSlices, nslices)) * bn::kStarCounterStride * sizeof(uint32_t);
   BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.barrier), counters));
   BN_HIP_CHECK(hipMemset(st.barrier, 0, counters));
   BN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.error), sizeof(int32_t), hipHostMallocMapped));
@@ -866,6 +931,9 @@ int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double l
   a.new_cpts = static_cast<T*>(new_cpts_dev);
   a.obs_off = fs->fused.begin()->second.d_obs_off;
   a.src = from_caller ? fs->fused.begin()->second.d_src : nullptr;
+  a.z_scratch = static_cast<T*>(fs->fused.begin()->second.z_state);
+  a.src_base = from_caller && st.stream ? fs->fused.begin()->second.src_base : nullptr;
+  a.src_stride = from_caller && st.stream ? fs->fused.begin()->second.src_stride : 0;
   a.cpt_off = g.d_cpt;
   a.root_cpt_off = p.cpt_off[st.root];
   a.K = (int32_t)g.nodes.size();
@@ -889,14 +957,23 @@ int launch_star(bn_plan* plan, int32_t num_iterations, int32_t average, double l
   a.ll_scale = average ? 1.0 / (double)p.N : 1.0;
   a.ll_out = ll_out_dev;
   constexpr int32_t V = 2, NW = bn::kStarWaves;
-  const size_t lds = (size_t)(NW / 2) * D0 * V * 64 * 12 + (size_t)NW * V * 64 * 12 + (size_t)D0 * V * 64 * 12 +
-                     (size_t)NW * 64 * sizeof(double) + (size_t)D0 * V * 64 * 12 +
-                     (size_t)st.chunk_len * D0 * 2 * sizeof(T);
-  const void* kernel = reinterpret_cast<const void*>(&bn::star_em_step<T, D0>);
-  static size_t lds_allowed[kMaxDevices] = {};  // per instantiation and device: the attribute is the device's
-  if (lds > 48 * 1024 && (p.device < 0 || p.device >= kMaxDevices || lds_allowed[p.device] < lds)) {
+  a.cpt_in_lds = 0;
+  size_t stream_lds = 0;
+  if (st.stream) {  // as prepare_star sized it
+    stream_lds = stream_lds_bytes(D0, st.chunk_len, sizeof(T), 80 * 1024, &a.cpt_in_lds);
+    if (!a.cpt_in_lds) stream_lds = stream_lds_bytes(D0, st.chunk_len, sizeof(T), 150 * 1024, &a.cpt_in_lds);
+  }
+  const size_t lds = st.stream ? stream_lds
+                               : (size_t)(NW / 2) * D0 * V * 64 * 12 + (size_t)NW * V * 64 * 12 + (size_t)D0 * V * 64 * 12 +
+                                     (size_t)NW * 64 * sizeof(double) + (size_t)D0 * V * 64 * 12 +
+                                     (size_t)st.chunk_len * D0 * 2 * sizeof(T);
+  const void* kernel = st.stream ? reinterpret_cast<const void*>(&bn::star_em_stream<T, D0>)
+                                 : reinterpret_cast<const void*>(&bn::star_em_step<T, D0>);
+  static size_t lds_allowed[2][kMaxDevices] = {};  // per instantiation and device: the attribute is the device's
+  size_t& allowed = lds_allowed[st.stream ? 1 : 0][p.device >= 0 && p.device < kMaxDevices ? p.device : 0];
+  if (lds > 48 * 1024 && (p.device < 0 || p.device >= kMaxDevices || allowed < lds)) {
     BN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (p.device >= 0 && p.device < kMaxDevices) lds_allowed[p.device] = lds;
+    if (p.device >= 0 && p.device < kMaxDevices) allowed = lds;
   }
   void* args[] = {&a};
   const uint32_t blocks = (uint32_t)(st.chunks * st.nslices);
@@ -999,6 +1076,7 @@ int launch_finish(bn_plan* plan, double learning_rate, double regularization, do
   a.D0 = g.dims[0];
   a.S = g.dims[1];
   a.slots = fam.slots_used;
+  a.forms = bn::form_sums_of(p, fam);
   a.cpts = static_cast<T*>(p.cpts);
   a.new_cpts = static_cast<T*>(new_cpts_dev);
   a.accum = plan->accum_slot;
@@ -1656,7 +1734,7 @@ int bn_em_statistics_static(bn_plan* plan, int32_t num_iterations, int32_t avera
     bool needed = bn::any_pending_fast(p) || !p.fresh;
     const int32_t reduce_last = accum_dev ? 1 : 2;
     for (size_t gi = 0; gi < p.vgroups.size() && !needed; ++gi)
-      needed = bn::variable_needs_arrays(p, gi, 1) || (num_iterations > 1 && bn::variable_needs_arrays(p, gi, 0));
+      needed = bn::variable_needs_arrays(p, gi, 1) || (num_iterations > 1 && bn::variable_needs_arrays(p, gi, 0, true));
     for (size_t fi = 0; fi < p.fgroups.size() && !needed; ++fi) {
       needed = bn::factor_needs_arrays(p, fi, 1, 1, num_iterations == 1 ? 1 : 0, reduce_last) ||
                (num_iterations > 1 && bn::factor_needs_arrays(p, fi, 0, 0, 1, reduce_last)) ||
@@ -1774,6 +1852,8 @@ static int step_evidence(bn_plan* plan, const void* const* evidence_dev, const u
     p.obs_pending = false;  // the first factor pass writes every observation array
     if (states_dev) {
       bn::set_ingest_next(p, true, true, on_value, off_value);
+      // ... and neither would anything read a copy of the state bytes
+      bn::set_states_in_caller(p, bn::caller_states_possible(p, num_iterations), on_value, off_value);
     } else {
       bn::set_ingest_next(p, true);
       // the plan is reset when the step ends: nothing would ever read its copy of the evidence
@@ -1814,7 +1894,8 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
       for (size_t i = 0; i < p.observed.size() && from_caller; ++i)
         from_caller = evidence_dev[i] && reinterpret_cast<uintptr_t>(evidence_dev[i]) % 32 == 0;
       if (from_caller) {
-        if (int rc = upload_family_sources(p, evidence_dev, s)) return rc;
+        // (the streaming kernel takes a base address and a distance where the arrays lie evenly: no table)
+        if (int rc = upload_family_sources(p, evidence_dev, s, nullptr, plan->star.stream)) return rc;
       } else {
         if (!p.observed.empty()) {
           const int rc = states_dev ? bn_enter_evidence_states(plan, states_dev, on_value, off_value, stream)
@@ -1898,6 +1979,7 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
       });
   bn::set_ingest_next(p, false);
   bn::set_evidence_in_caller(p, false);
+  bn::set_states_in_caller(p, false);
   if (rc != BN_OK) return rc;
   if (from_graph)
     BN_HIP_CHECK(hipMemcpyAsync(new_cpts_dev, p.cpts, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice, s));
@@ -1934,6 +2016,7 @@ int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const 
   t_discard_last_messages = false;
   bn::set_ingest_next(p, false);
   bn::set_evidence_in_caller(p, false);
+  bn::set_states_in_caller(p, false);
   if (rc != BN_OK) return rc;
   prof_begin("log_likelihood", (double)p.N * 8.0, s);
   bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, average ? 1.0 / (double)p.N : 1.0, ll_out_dev);

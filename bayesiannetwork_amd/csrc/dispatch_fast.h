@@ -139,6 +139,30 @@ inline void set_evidence_in_caller(Plan& p, bool on) {
   if (FastState* st = fast_state(p)) st->evidence_in_caller = on;
 }
 
+// Can the launches that read compact hard evidence in place serve this group (its shape, room in LDS
+// for a chunk's rows, room for the step's records)?  Defined next to those kernels (leaf_f32.hip).
+bool hard_family_possible(const Plan& p, const FactorGroup& g, const FusedFamily& fam);
+
+// The same question for compact hard evidence (kernels_hard.h): float plans, every leaf of every
+// fused group an observed two-state leaf under one parent of at most 16 states, their state rows at
+// equal distances.
+inline bool caller_states_possible(const Plan& p, int32_t num_iterations) {
+  FastState* st = fast_state(p);
+  if (!st || !st->ingest_ok || !st->ingest_all_observed || p.dtype != 0 || p.tile != 256 || num_iterations < 3) return false;
+  if (env_copy_evidence() || env_no_recompute()) return false;
+  for (const auto& kv : st->fused)
+    if (kv.second.wide_index2 >= 0 || !hard_family_possible(p, p.fgroups[kv.first], kv.second)) return false;
+  return !st->fused.empty();
+}
+
+inline void set_states_in_caller(Plan& p, bool on, double on_value = 1.0, double off_value = 0.0) {
+  if (FastState* st = fast_state(p)) {
+    st->states_in_caller = on;
+    st->states_on = on_value;
+    st->states_off = off_value;
+  }
+}
+
 inline void set_ingest_next(Plan& p, bool on, bool from_states = false, double on_value = 1.0, double off_value = 0.0) {
   if (FastState* st = fast_state(p)) {
     st->ingest_next = on;
@@ -577,7 +601,9 @@ inline int prepare_fast(Plan& p) {
 
 // Does the variable-pass launch of group gi read or write a message array of the lazy region?
 // (Asked while that region has no memory yet: the caller then backs it before the launch.)
-inline bool variable_needs_arrays(const Plan& p, size_t gi, int32_t fresh) {
+// after_first: the question is about a later iteration of a call whose first one runs on fresh
+// messages (asked before the call starts: the fused kernels will have written the partial products by then)
+inline bool variable_needs_arrays(const Plan& p, size_t gi, int32_t fresh, bool after_first = false) {
   FastState* st = fast_state(p);
   if (!st) return true;
   if (st->vgroup_skip[gi]) return false;
@@ -587,7 +613,7 @@ inline bool variable_needs_arrays(const Plan& p, size_t gi, int32_t fresh) {
     const bool fused = w.fused_fgroup >= 0;
     if (w.uncovered_lazy) return true;
     // covered slots: read by the standalone product, read and written by the standalone emission
-    if (w.covered_lazy && (!fused || (!fresh && !w.partials_valid))) return true;
+    if (w.covered_lazy && (!fused || (!fresh && !w.partials_valid && !after_first))) return true;
   }
   return false;
 }
@@ -981,6 +1007,9 @@ inline void append_state_signature(const Plan& p, std::string& key) {
   auto put = [&](const auto& v) { key.append(reinterpret_cast<const char*>(&v), sizeof v); };
   put(st->ingest_next);
   put(st->evidence_in_caller);
+  put(st->states_in_caller);
+  put(st->states_on);
+  put(st->states_off);
   put(st->ingest_states);
   put(st->ingest_on);
   put(st->ingest_off);
@@ -1002,6 +1031,7 @@ inline void append_state_signature(const Plan& p, std::string& key) {
     put(fam.src_stride);
     put(fam.ll_rows);
     put(fam.slots_used);
+    put(fam.em_by_form);
   }
 }
 
@@ -1046,6 +1076,13 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
   return used;
 }
 
+// how the last reduce-mode launch of a fused group left its count sums
+inline FormSums form_sums_of(const Plan& p, const FusedFamily& fam) {
+  FastState* st = fast_state(p);
+  if (!fam.em_by_form) return FormSums{nullptr, 0.f, 0.f};
+  return FormSums{static_cast<const float*>(fam.z_state), (float)st->states_on, (float)st->states_off};
+}
+
 // EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.
 // listed: other entries to finalise from their chunk partial sums in the same launch (count 0 = none).
 inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s, ListedEntries listed = ListedEntries{nullptr, nullptr, 0, 0}) {
@@ -1056,14 +1093,15 @@ inline int finalize_em_fast(Plan& p, size_t fi, double* accum, hipStream_t s, Li
   FactorGroup& g = p.fgroups[fi];
   const int64_t items = (int64_t)g.nodes.size() * g.cpt_elems;
   const uint32_t blocks = wave_blocks(items) + (uint32_t)((listed.count + kWavesPerBlock - 1) / kWavesPerBlock);
+  const FormSums forms = form_sums_of(p, it->second);
   if (p.dtype == 0) {
     launch(em_finalize_slots<float>, dim3(blocks), dim3(256), 0, s,
            static_cast<const float*>(it->second.em_partial), static_cast<const float*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed, forms);
   } else {
     launch(em_finalize_slots<double>, dim3(blocks), dim3(256), 0, s,
            static_cast<const double*>(it->second.em_partial), static_cast<const double*>(p.cpts), g.d_cpt,
-           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed);
+           (int32_t)g.nodes.size(), (int32_t)g.cpt_elems, it->second.slots_used, accum, listed, forms);
   }
   return launch_ok() ? 1 : -1;
 }

@@ -7,6 +7,7 @@
 
 #include "fast_state.h"
 #include "kernels_leaf.h"
+#include "kernels_hard.h"
 #include "kernels_leaf_loop.h"
 #include "launch.h"
 
@@ -103,6 +104,135 @@ inline LeafFamilyFn<T> leaf_family_p2_lookup(int32_t d0, int32_t d1, int32_t s) 
   return nullptr;
 }
 
+// The launches of a step that reads compact hard evidence where the caller holds it (kernels_hard.h).
+// Same contract as launch_leaf_family, for the three launches such a step consists of; -1 for any other.
+using HardFn = void (*)(const float*, LeafFamilyArgs<float>);
+using HardTablesFn = void (*)(const float*, LeafFamilyArgs<float>, float*);
+struct HardKernels {
+  HardFn first = nullptr, light = nullptr, reduce = nullptr;
+  HardTablesFn tables = nullptr;
+  size_t (*first_lds)(int32_t) = nullptr, (*rows_lds)(int32_t) = nullptr;  // staged rows of a chunk of that many families
+};
+template <int D0>
+inline HardKernels hard_kernels_for() {
+  if constexpr (D0 <= 16)
+    return {hard_loop_first<D0>, hard_loop_light<D0>, hard_reduce_mfma<D0>, hard_tables_build<D0>,
+            HardStage<D0, true>::bytes, HardStage<D0, false>::bytes};
+  return {};
+}
+inline HardKernels hard_kernels(int32_t d0) {
+  switch (d0) {
+#define X(DV) \
+  case DV:    \
+    return hard_kernels_for<DV>();
+    BN_PARENT_DIMS(X)
+#undef X
+  }
+  return {};
+}
+
+constexpr size_t kHardLdsMax = 64 * 1024;  // per block, so that at least two blocks share a CU
+
+// the reduce launch's own cut of a group's K families: chunk length (whole groups of eight)
+inline int32_t hard_reduce_chunk_len(const Plan& p, int32_t K, int32_t rows_cap) {
+  int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * 2));  // about four resident waves per SIMD
+  if (env_reduce_chunks() > 0) want = env_reduce_chunks();
+  const int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, rows_cap), K));
+  const int32_t len = (K + chunks - 1) / chunks;
+  return (len + kHardGroup - 1) / kHardGroup * kHardGroup;
+}
+
+// Can the three launches serve this group (shape, room in LDS, room for the step's records)?
+inline bool hard_family_fits(const Plan& p, const FactorGroup& g, const FusedFamily& fam) {
+  const HardKernels kernels = hard_kernels(g.dims[0]);
+  const int32_t K = (int32_t)g.nodes.size();
+  if (!kernels.first || g.dims[1] != 2 || fam.src_stride == 0 || !fam.z_state) return false;
+  if (hard_state_floats(K, g.dims[0]) > (size_t)K * (size_t)p.npad) return false;
+  if (kernels.first_lds(fam.chunk_len) > kHardLdsMax) return false;
+  return kHardSBytes + kernels.rows_lds(hard_reduce_chunk_len(p, K, fam.ll_rows_cap)) <= kHardLdsMax;
+}
+
+inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, const float* cpts, int32_t fresh,
+                              int32_t first_iteration, int32_t mode, hipStream_t s, bool with_counts, int32_t next_is_last) {
+  const HardKernels kernels = hard_kernels(g.dims[0]);
+  if (!hard_family_fits(p, g, fam)) return -1;
+  // The step's records live where a step of this kind keeps nothing else: in the per-family loop-state
+  // normalisers (its loop launches leave chunk products, its reduce launch forms the z again).
+  LeafFamilyArgs<float> a{};
+  a.hard_tab = static_cast<const float*>(fam.z_state);
+  a.cpt_off = g.d_cpt;
+  a.K = (int32_t)g.nodes.size();
+  a.chunks = fam.chunks;
+  a.chunk_len = fam.chunk_len;
+  a.chunk_base = fam.chunk_base;
+  a.part_mant = w.part_mant;
+  a.part_exp = w.part_exp;
+  a.zdiv_mant = w.zdiv_mant[w.zd_read];
+  a.zdiv_exp = w.zdiv_exp[w.zd_read];
+  a.zdiv_next_mant = w.zdiv_mant[w.zd_read ^ 1];
+  a.zdiv_next_exp = w.zdiv_exp[w.zd_read ^ 1];
+  a.scaled = w.scaled;
+  a.scaled_prev = w.scaled_prev;
+  a.npad = p.npad;
+  a.ntiles = p.ntiles;
+  a.N = p.N;
+  a.em_partial = with_counts ? static_cast<float*>(fam.em_partial) : nullptr;
+  a.slots = fam.slots;
+  a.ll_part = fam.ll_part;
+  a.src_base = fam.src_base;
+  a.src_stride = fam.src_stride;
+  a.on_value = (float)fast_state(p)->states_on;
+  a.off_value = (float)fast_state(p)->states_off;
+  HardFn fn = nullptr;
+  size_t lds_bytes = 0;
+  if (mode == kLeafLoop) {
+    if (next_is_last) return -1;  // (the launch before the reduce launch is left out: leaf_launch_folds)
+    if (fresh) {
+      fn = kernels.first;
+      lds_bytes = kernels.first_lds(a.chunk_len);
+    } else {
+      if (first_iteration || fam.z_form != kZPerChunk) return -1;
+      fn = kernels.light;
+      lds_bytes = kernels.rows_lds(a.chunk_len);
+    }
+  } else if (mode == kLeafReduce) {
+    if (fresh || first_iteration || fam.z_form != kZRecompute) return -1;
+    fn = kernels.reduce;
+    a.chunk_len = hard_reduce_chunk_len(p, a.K, fam.ll_rows_cap);
+    a.chunks = (a.K + a.chunk_len - 1) / a.chunk_len;
+    a.slots = (int32_t)(p.ntiles * 2);
+    lds_bytes = kHardSBytes + kernels.rows_lds(a.chunk_len);
+  } else {
+    return -1;
+  }
+  if (lds_bytes > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+    return -1;
+  if (fn == kernels.first) {
+    // the parameters are the step's: one set of records serves all its launches
+    launch(kernels.tables, dim3((uint32_t)(((size_t)a.K * g.dims[0] + 255) / 256)), dim3(256), 0, s, cpts, a, static_cast<float*>(fam.z_state));
+    if (!launch_ok()) return -1;
+  }
+  launch(fn, dim3(hard_blocks(a.chunks, p.ntiles)), dim3(256), lds_bytes, s, cpts, a);
+  if (!launch_ok()) return -1;
+  if (mode == kLeafLoop) {
+    fam.z_form = kZPerChunk;
+    fam.pending = false;
+    fam.em_ready = false;
+    w.partials_valid = true;
+    if (fresh) w.products_cached = false;  // the first launch rewrote the chunks' partial products
+  } else {
+    fam.ll_rows = a.chunks;
+    fam.slots_used = a.slots;
+    fam.em_by_form = true;
+    fam.pending = true;
+    fam.pending_fresh = fresh;
+    fam.pending_first = first_iteration;
+    fam.em_ready = with_counts;
+  }
+  return 1;
+}
+
 // w2: the second wide parent of a two-parent family group, nullptr for one-parent groups
 template <typename T>
 int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, WideNode* w2, T* arena, const T* cpts,
@@ -116,6 +246,10 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     fam.pending = false;
     fam.em_ready = false;
     return 1;
+  }
+  if constexpr (std::is_same<T, float>::value) {
+    if (fast_state(p)->states_in_caller && !w2 && g.dims[1] == 2)
+      return launch_hard_family(p, g, fam, w, cpts, fresh, first_iteration, mode, s, with_counts, next_is_last);
   }
   const int32_t state = fresh ? kLeafFresh
                               : (first_iteration ? kLeafFromArrays : (fam.z_form == kZRecompute ? kLeafRecompute : kLeafSteady));
@@ -284,6 +418,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   if (mode == kLeafReduce) {
     fam.ll_rows = a.chunks;
     fam.slots_used = a.slots;
+    fam.em_by_form = false;
     fam.pending = true;
     fam.pending_fresh = fresh;
     fam.pending_first = first_iteration;

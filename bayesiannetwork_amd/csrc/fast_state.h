@@ -83,6 +83,7 @@ struct FusedFamily {
   int32_t ll_rows = 0;          // rows the last reduce-mode launch wrote
   int32_t ll_rows_cap = 0;      // rows allocated
   int32_t slots_used = 0;       // per-wave sum slots the last reduce-mode launch wrote
+  bool em_by_form = false;      // ... as sums by evidence form (kernels_hard.h), not by CPT entry
   // the last iteration ran in reduce mode: stored messages are one iteration behind until
   // complete_pending_fast re-runs it in full mode with these flags
   bool pending = false;
@@ -141,6 +142,9 @@ struct FastState {
   // An EM step (bn_em_step) on such a plan: no launch of the call copies the evidence, they all read
   // the caller's arrays (the plan is reset when the step ends, the copy would never be read again).
   bool evidence_in_caller = false;
+  // ... and the same for compact hard evidence: every launch reads the caller's state bytes (kernels_hard.h)
+  bool states_in_caller = false;
+  double states_on = 1.0, states_off = 0.0;  // what the state bytes stand for, for the whole step
 };
 
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).

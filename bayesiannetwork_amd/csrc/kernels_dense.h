@@ -319,13 +319,29 @@ __global__ void __launch_bounds__(256) em_p1_mfma(const float* __restrict__ aren
   const int64_t t0 = chunk * per;
   const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
 
+  // The matrix instruction accumulates in float: a tile's 256 observations at a time, then the
+  // tile's sums go into double running sums (a float running sum over a chunk of thousands of
+  // observations loses up to 4e-5 relative on the small entries of a 64 x 64 count matrix).
   f32x16 acc[kPerWave];
+  double total[kPerWave][16];
 #pragma unroll
   for (int32_t q = 0; q < kPerWave; ++q)
 #pragma unroll
-    for (int32_t r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int32_t r = 0; r < 16; ++r) {
+      acc[q][r] = 0.f;
+      total[q][r] = 0.0;
+    }
 
   for (int64_t t = t0; t < t1; ++t) {
+    if (t > t0) {
+#pragma unroll
+      for (int32_t q = 0; q < kPerWave; ++q)
+#pragma unroll
+        for (int32_t r = 0; r < 16; ++r) {
+          total[q][r] += (double)acc[q][r];
+          acc[q][r] = 0.f;
+        }
+    }
     for (int32_t quarter = 0; quarter < 4; ++quarter) {
       const int64_t n0 = t * kTile + quarter * 64;
       if (n0 >= N) break;
@@ -374,7 +390,7 @@ __global__ void __launch_bounds__(256) em_p1_mfma(const float* __restrict__ aren
 #pragma unroll
       for (int32_t r = 0; r < 16; ++r) {
         const int32_t a = 32 * it + mfma_row(r, lane), b = 32 * jt + col;
-        partial[(cpt_off[k] + (int64_t)a * S + b) * nchunks + chunk] = (double)acc[q][r];
+        partial[(cpt_off[k] + (int64_t)a * S + b) * nchunks + chunk] = total[q][r] + (double)acc[q][r];
       }
     }
   }

@@ -48,6 +48,7 @@ struct FinishArgs {
   double ll_scale;
   double* ll_out;  // may be null: the caller sums ll_partial itself
   uint32_t* arrived;  // zero between launches
+  FormSums forms;     // tab != nullptr: em_partial holds sums by evidence form (two-state leaves)
 };
 
 // one CPT row: target = counts / sum, regularised and blended as in m_step_rows (no fused multiply-add)
@@ -103,12 +104,25 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
       for (int32_t sl = lane; sl < a.slots; sl += 64) acc += (double)src[sl];
 #pragma unroll
       for (int32_t o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-      return acc * (double)a.cpts[off + j];
+      return acc;
     };
     if (a.S <= 4) {  // the usual leaves: the row stays in registers
       double counts[4];
 #pragma unroll
       for (int32_t j = 0; j < 4; ++j) counts[j] = j < a.S ? entry_sum(j) : 0.0;
+      if (a.forms.tab) {
+        const float* rec = a.forms.tab + (size_t)k * (kHardRows * a.D0);
+        const double g0 = counts[0] + hard_third_sum(a.forms.tab, a.K, a.D0, k, 0, d);
+        const double g1 = counts[1] + hard_third_sum(a.forms.tab, a.K, a.D0, k, 1, d);
+#pragma unroll
+        for (int32_t j = 0; j < 2; ++j)
+          counts[j] = hard_count(g0, g1, rec[kHardRq * a.D0 + d], rec[(kHardRq + 1) * a.D0 + d], j, a.forms.on,
+                                 a.forms.off, (double)a.cpts[off + j]);
+      } else {
+#pragma unroll
+        for (int32_t j = 0; j < 4; ++j)
+          if (j < a.S) counts[j] = counts[j] * (double)a.cpts[off + j];
+      }
       if (lane == 0) {
         if (a.accum) {
 #pragma unroll
@@ -119,7 +133,7 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
       }
     } else {
       double counts[kFinishMaxStates];
-      for (int32_t j = 0; j < a.S; ++j) counts[j] = entry_sum(j);
+      for (int32_t j = 0; j < a.S; ++j) counts[j] = entry_sum(j) * (double)a.cpts[off + j];
       if (lane == 0) {
         if (a.accum)
           for (int32_t j = 0; j < a.S; ++j) a.accum[off + j] = counts[j];

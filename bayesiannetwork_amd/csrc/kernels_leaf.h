@@ -51,6 +51,8 @@ struct LeafFamilyArgs {
   // is read (src_stride = 0: use the table)
   const unsigned char* src_base;
   int64_t src_stride;
+  // compact hard evidence read in place (kernels_hard.h): the step's tables of q and 1 / q per evidence form
+  const float* hard_tab;
   T on_value, off_value;  // evidence given as states: what an observed / any other state's row receives
   // leaf_loop_p1 only: 1, or kWavesPerBlock when the waves of a block share one (chunk, tile, part)
   // work item, each taking a quarter of the chunk's families (small batches: as many waves as
@@ -984,12 +986,50 @@ struct ListedEntries {
   int32_t nchunks;
 };
 
+// Count sums a reduce launch over compact hard evidence left by evidence form instead of by CPT entry
+// (kernels_hard.h: hard_reduce, hard_count): the group's records and what the state bytes stand for.
+// tab == nullptr: sums by entry.
+struct FormSums {
+  const float* tab;
+  float on, off;
+};
+
+constexpr int32_t kHardForms = 3;  // evidence forms of a two-state leaf: state 0, state 1, neither
+// One record per family, the same for all lanes and read through the scalar cache: rows of D0 floats
+//   0..2  q[y][d] = cpt[d] . ev(y) for the three evidence forms
+//   3..5  1 / q[y][d]
+//   6..7  how an observation of the third form enters the sums of the first two (hard_reduce)
+//   8..13 three rows of doubles: log2 q[0][d], log2 q[1][d] - log2 q[0][d], log2 q[2][d] - log2 q[0][d]
+//         (a q of zero counts as 2^kHardLogOfZero)
+constexpr int32_t kHardRows = 14, kHardQ = 0, kHardRq = 3, kHardThird = 6, kHardLog = 8;
+constexpr double kHardLogOfZero = -1.0e6;
+
+// evidence row j of a two-state leaf whose evidence has form y (0, 1; 2: neither state)
+__device__ __forceinline__ float hard_ev(int32_t y, int32_t j, float on, float off) { return y == j ? on : off; }
+
+// counts[d][j] of a family from its sums by form, G[y][d] = sum over the observations of form y of
+// P'[d] * scale:  cpt[d][j] * (ev(0)[j] * G[0][d] / q[0][d] + ev(1)[j] * G[1][d] / q[1][d])
+// the sums of family k's third-form observations for form y, state d (behind the K records)
+__device__ __forceinline__ double hard_third_sum(const float* tab, int32_t K, int32_t d0, int32_t k, int32_t y, int32_t d) {
+  return (double)tab[(size_t)K * (kHardRows * d0) + (size_t)k * (2 * d0) + (size_t)y * d0 + d];
+}
+
+__device__ __forceinline__ double hard_count(double g0, double g1, float rq0, float rq1, int32_t j, float on, float off,
+                                             double cpt) {
+#pragma clang fp contract(off)
+  const double x0 = ((double)rq0 * (double)hard_ev(0, j, on, off)) * g0;
+  const double x1 = ((double)rq1 * (double)hard_ev(1, j, on, off)) * g1;
+  return (x0 + x1) * cpt;
+}
+
+
+
 template <typename T>
 __global__ void __launch_bounds__(256) em_finalize_slots(const T* __restrict__ em_partial,
                                                         const T* __restrict__ cpts,
                                                         const int64_t* __restrict__ cpt_off, int32_t K,
                                                         int32_t entries_per_node, int32_t slots,
-                                                        double* __restrict__ accum, ListedEntries listed) {
+                                                        double* __restrict__ accum, ListedEntries listed, FormSums forms) {
   const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t own = (((int64_t)K * entries_per_node + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
@@ -1008,11 +1048,26 @@ __global__ void __launch_bounds__(256) em_finalize_slots(const T* __restrict__ e
   if (item >= (int64_t)K * entries_per_node) return;
   const int32_t k = (int32_t)(item / entries_per_node);
   const int32_t e = (int32_t)(item % entries_per_node);
-  const T* src = em_partial + item * slots;
-  double acc = 0.0;
-  for (int32_t sl = lane; sl < slots; sl += 64) acc += (double)src[sl];
+  auto slot_sum = [&](int64_t entry) {
+    const T* src = em_partial + entry * slots;
+    double acc = 0.0;
+    for (int32_t sl = lane; sl < slots; sl += 64) acc += (double)src[sl];
 #pragma unroll
-  for (int32_t off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    for (int32_t off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+  };
+  if (forms.tab) {
+    // two-state leaves: entry e = (d, j); the sums of forms 0 and 1 lie where entries (d, 0), (d, 1) would
+    const int32_t d = e >> 1, j = e & 1, d0 = entries_per_node >> 1;
+    const double g0 = slot_sum(item - j) + hard_third_sum(forms.tab, K, d0, k, 0, d);
+    const double g1 = slot_sum(item - j + 1) + hard_third_sum(forms.tab, K, d0, k, 1, d);
+    const float* rec = forms.tab + (size_t)k * (kHardRows * d0);
+    if (lane == 0)
+      accum[cpt_off[k] + e] = hard_count(g0, g1, rec[kHardRq * d0 + d], rec[(kHardRq + 1) * d0 + d], j, forms.on,
+                                         forms.off, (double)cpts[cpt_off[k] + e]);
+    return;
+  }
+  const double acc = slot_sum(item);
   if (lane == 0) accum[cpt_off[k] + e] = acc * (double)cpts[cpt_off[k] + e];
 }
 

@@ -50,6 +50,14 @@ struct StarArgs {
   // for a leaf that is not observed, its all-ones array in the arena, which has the same shape up
   // to N).  The plan's own copy is not needed: the step ends with the plan reset.
   const void* const* src;
+  // star_em_stream only: the leaves' normalisers between two iterations ([K][npad]; every lane reads
+  // back what it wrote itself)
+  T* z_scratch;
+  // ... and, when the caller's arrays lie at equal distances, leaf k's is src_base + k * src_stride
+  // bytes and `src` is not read (src_stride = 0: `src` is)
+  const unsigned char* src_base;
+  int64_t src_stride;
+  int32_t cpt_in_lds;  // star_em_stream: the launch has room for the block's CPT rows in LDS
   const int64_t* cpt_off;  // [K] element offset of each leaf's CPT
   int64_t root_cpt_off;
   int32_t K, C, chunk_len, nslices, iterations;
@@ -613,6 +621,570 @@ __global__ void __launch_bounds__(64 * kStarWaves) star_em_step(StarArgs<T> a) {
     __syncthreads();  // red[] was read by thread 0 before the barrier
     if (lane == 0) red[wave] = mine;
     if (threadIdx.x < D0) red[NW + threadIdx.x] = root_count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double counts[D0];
+      for (int32_t d = 0; d < D0; ++d) counts[d] = red[NW + d];
+      new_row(a.root_cpt_off, D0, counts);
+      double ll = 0.0;
+      for (int32_t w = 0; w < NW; ++w) ll += red[w];
+      *a.ll_out = ll * a.ll_scale;
+    }
+  }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------
+// The same one-launch EM step for batches whose evidence no longer fits the registers of the resident
+// waves (about a thousand to a few tens of thousands of observations): star_em_stream.
+//
+//   block (c, sl) as in star_em_step, but a wave walks its families one after the other in every
+//   iteration, reading their evidence again (the block reads nothing but its own chunk's evidence:
+//   the re-reads come from the L2 of the XCD it sits on) and keeping a family's normaliser for the
+//   next iteration in global scratch instead of a register.  The first pass forms prod q and the
+//   first iteration's values together; the waves' products meet in LDS two at a time (30 KB instead
+//   of a buffer per pair), so that two blocks fit on a CU: the launch may have twice as many blocks
+//   as the chip has CUs, four waves per SIMD, each with half as many families to walk.  After the grid-wide barrier ALL blocks share the M-step (a wave
+//   per CPT row, the lanes fetching the slices' count sums side by side).
+constexpr int32_t kStreamMaxSlices = 256;
+
+template <typename T, int D0>
+__global__ void __launch_bounds__(64 * kStarWaves) star_em_stream(StarArgs<T> a) {
+  constexpr int32_t S = 2, V = 2, E = D0 * S, NW = kStarWaves;
+  constexpr int32_t kTileT = tile_of<T>::value;
+  extern __shared__ __align__(16) unsigned char star_lds[];
+  // LDS: two merge buffers (D0*V doubles + D0*V ints per lane each; the combine's per-state products
+  // live in the first one, which is free once the first pass has ended), the waves' prod z, block
+  // reductions, the block's prod q, the block's CPT rows
+  double* merge_m = reinterpret_cast<double*>(star_lds);
+  int32_t* merge_e = reinterpret_cast<int32_t*>(merge_m + (size_t)2 * D0 * V * 64);
+  double* z_m = reinterpret_cast<double*>(merge_e + (size_t)2 * D0 * V * 64);
+  int32_t* z_e = reinterpret_cast<int32_t*>(z_m + (size_t)NW * V * 64);
+  double* st_m = merge_m;
+  int32_t* st_e = merge_e;
+  double* red = reinterpret_cast<double*>(z_e + (size_t)NW * V * 64);  // [NW * 64]
+  double* bq_m = red + NW * 64;                                          // [D0][V][64]
+  int32_t* bq_e = reinterpret_cast<int32_t*>(bq_m + (size_t)D0 * V * 64);
+  // the CPT rows of the block's families, when the host found room for them (a.cpt_in_lds): fetched by
+  // all threads at once instead of two scalar round trips per family and iteration
+  T* cpt_lds = reinterpret_cast<T*>(bq_e + (size_t)D0 * V * 64);
+
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int32_t c = (int32_t)blockIdx.x / a.nslices, sl = (int32_t)blockIdx.x % a.nslices;
+  const int32_t nblocks = a.C * a.nslices;
+  const int64_t obs0 = (int64_t)sl * kStarSlice + lane * V;
+  const int64_t t = obs0 / kTileT;
+  const int32_t col = (int32_t)(obs0 % kTileT);
+  uint32_t slice_epoch = a.slice_epoch0;
+  uint32_t* slice_counter = a.barrier + (size_t)(1 + sl) * kStarCounterStride;
+
+  const int32_t fb0 = c * a.chunk_len;
+  const int32_t fb1 = fb0 + a.chunk_len < a.K ? fb0 + a.chunk_len : a.K;
+  const int32_t per_wave = (fb1 - fb0 + NW - 1) / NW;
+  const int32_t lo = fb0 + wave * per_wave < fb1 ? fb0 + wave * per_wave : fb1;
+  const int32_t hi = lo + per_wave < fb1 ? lo + per_wave : fb1;
+
+  // this lane's evidence of family k (padding observations, and the second one of an odd batch's
+  // last lane, count as all ones)
+  auto load_ev = [&](int32_t k, fv<T, V>* ev) {
+    if (a.src || a.src_stride) {
+      ev[0] = splat<T, V>((T)1);
+      ev[1] = splat<T, V>((T)1);
+      if (obs0 < a.N) {
+        const T* rows = (a.src_stride ? reinterpret_cast<const T*>(a.src_base + (int64_t)k * a.src_stride)
+                                      : static_cast<const T*>(a.src[k])) + obs0 * S;
+        if (obs0 + 1 < a.N) {
+          const fv<T, 4> raw = *reinterpret_cast<const fv<T, 4>*>(rows);
+          ev[0][0] = raw[0];
+          ev[1][0] = raw[1];
+          ev[0][1] = raw[2];
+          ev[1][1] = raw[3];
+        } else {
+          ev[0][0] = rows[0];
+          ev[1][0] = rows[1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) ev[j] = loadv<T, V>(a.arena + a.obs_off[k], t * S + j, col);
+    }
+  };
+  if (a.cpt_in_lds) {
+    for (int32_t i = threadIdx.x; i < (fb1 - fb0) * E; i += 64 * NW) cpt_lds[i] = a.cpts[a.cpt_off[fb0 + i / E] + i % E];
+    __syncthreads();
+  }
+  auto family_q = [&](int32_t k, const fv<T, V>* ev, fv<T, V>* q) {
+    const T* cpt = a.cpt_in_lds ? cpt_lds + (size_t)(k - fb0) * E : a.cpts + a.cpt_off[k];  // (wave-uniform)
+#pragma unroll
+    for (int32_t d = 0; d < D0; ++d) {
+      q[d] = cpt[d * S] * ev[0];
+#pragma unroll
+      for (int32_t j = 1; j < S; ++j) q[d] = __builtin_elementwise_fma(splat<T, V>(cpt[d * S + j]), ev[j], q[d]);
+    }
+  };
+  T* zs = a.z_scratch + t * kTileT + col;  // + k * npad: this lane's two normalisers of family k
+  // The wave's families one after the other, the evidence (and, with_z, the stored normaliser) of
+  // four of them in flight: body(k, ev, z).
+  constexpr int32_t kRing = 4;
+  auto walk = [&](bool with_z, auto&& body) {
+    fv<T, V> ring_ev[kRing][S];
+    fv<T, V> ring_z[kRing];
+#pragma unroll
+    for (int32_t u = 0; u < kRing; ++u) {
+      ring_z[u] = splat<T, V>((T)1);
+      if (lo + u < hi) {
+        load_ev(lo + u, ring_ev[u]);
+        if (with_z) ring_z[u] = *reinterpret_cast<const fv<T, V>*>(zs + (int64_t)(lo + u) * a.npad);
+      }
+    }
+    for (int32_t k0 = lo; k0 < hi; k0 += kRing) {
+#pragma unroll
+      for (int32_t u = 0; u < kRing; ++u) {
+        const int32_t k = k0 + u;
+        if (k < hi) {
+          body(k, ring_ev[u], ring_z[u]);
+          if (k + kRing < hi) {
+            load_ev(k + kRing, ring_ev[u]);
+            if (with_z) ring_z[u] = *reinterpret_cast<const fv<T, V>*>(zs + (int64_t)(k + kRing) * a.npad);
+          }
+        }
+      }
+    }
+  };
+  const T* prior = a.cpts + a.root_cpt_off;
+
+  // the block's partial product prod q / prod z of this iteration's messages to the root, into the
+  // partial-product buffer of iteration `it`
+  auto publish = [&](int32_t it, const double* zm, const int32_t* ze) {
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      z_m[(wave * V + v) * 64 + lane] = zm[v];
+      z_e[(wave * V + v) * 64 + lane] = ze[v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double inv_z[V];
+      int32_t ez[V];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        double m = 1.0;
+        int32_t e = 0;
+#pragma unroll
+        for (int32_t w = 0; w < NW; ++w) {
+          int de = 0;
+          m = frexp(m * z_m[(w * V + v) * 64 + lane], &de);
+          e += z_e[(w * V + v) * 64 + lane] + de;
+        }
+        inv_z[v] = 1.0 / m;
+        ez[v] = e;
+      }
+      double* pm = a.part_mant + (size_t)(it & 1) * a.C * D0 * a.npad;
+      int32_t* pe = a.part_exp + (size_t)(it & 1) * a.C * D0 * a.npad;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        const int64_t row = ((int64_t)c * D0 + d) * a.npad + obs0;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          const double m = frexp(bq_m[(d * V + v) * 64 + lane] * inv_z[v], &de);
+          shared_store(pm + row + v, m);
+          shared_store(pe + row + v, bq_e[(d * V + v) * 64 + lane] + de - ez[v]);
+        }
+      }
+    }
+  };
+
+  // ---- first pass: prod_k q_k[d] over the wave's families, and iteration 1 (every message uniform)
+  double qm[D0][V];
+  int32_t qe[D0][V];
+#pragma unroll
+  for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      qm[d][v] = 1.0;
+      qe[d][v] = 0;
+    }
+  {
+    double zm[V] = {1.0, 1.0};
+    int32_t ze[V] = {0, 0};
+    int32_t until = 4;  // four float factors cannot leave the double range
+    walk(false, [&](int32_t k, const fv<T, V>* ev, const fv<T, V>&) {
+      fv<T, V> q[D0];
+      family_q(k, ev, q);
+      fv<T, V> own[S];
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) own[j] = splat<T, V>((T)1 / (T)S);
+      const fv<T, V> zc = leaf_normaliser<T, S, V>(ev, own);
+      fv<T, V> sum_r = splat<T, V>(0.f), acc = splat<T, V>(0.f);
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        const fv<T, V> r = splat<T, V>((T)1) * rcpv<T, V>(splat<T, V>((T)1 / (T)D0));
+        sum_r += r;
+        acc = __builtin_elementwise_fma(r, q[d], acc);
+      }
+      const fv<T, V> zn = acc * rcpv<T, V>(sum_r);
+      *reinterpret_cast<fv<T, V>*>(zs + (int64_t)k * a.npad) = zn;
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        zm[v] *= (double)zc[v];
+#pragma unroll
+        for (int32_t d = 0; d < D0; ++d) qm[d][v] *= (double)q[d][v];
+      }
+      if (--until == 0 || sizeof(T) == 8) {
+        until = 4;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          zm[v] = frexp(zm[v], &de);
+          ze[v] += de;
+#pragma unroll
+          for (int32_t d = 0; d < D0; ++d) {
+            qm[d][v] = frexp(qm[d][v], &de);
+            qe[d][v] += de;
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      zm[v] = frexp(zm[v], &de);
+      ze[v] += de;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        qm[d][v] = frexp(qm[d][v], &de);
+        qe[d][v] += de;
+      }
+    }
+    // the waves' prod q meet in wave 0, two writers at a time: (4,5)->(0,1), (6,7)->(2,3), (2,3)->(0,1), 1->0
+    auto hand_over = [&](int32_t from0, int32_t to0, int32_t count) {
+      __syncthreads();
+      if (wave >= from0 && wave < from0 + count) {
+        double* dm = merge_m + (size_t)(wave - from0) * D0 * V * 64;
+        int32_t* de = merge_e + (size_t)(wave - from0) * D0 * V * 64;
+#pragma unroll
+        for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) {
+            dm[(d * V + v) * 64 + lane] = qm[d][v];
+            de[(d * V + v) * 64 + lane] = qe[d][v];
+          }
+      }
+      __syncthreads();
+      if (wave >= to0 && wave < to0 + count) {
+        const double* dm = merge_m + (size_t)(wave - to0) * D0 * V * 64;
+        const int32_t* de = merge_e + (size_t)(wave - to0) * D0 * V * 64;
+#pragma unroll
+        for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) {
+            int x = 0;
+            qm[d][v] = frexp(qm[d][v] * dm[(d * V + v) * 64 + lane], &x);
+            qe[d][v] += de[(d * V + v) * 64 + lane] + x;
+          }
+      }
+    };
+    static_assert(NW == 8, "the hand-over schedule is written for eight waves");
+    hand_over(4, 0, 2);
+    hand_over(6, 2, 2);
+    hand_over(2, 0, 2);
+    hand_over(1, 0, 1);
+    if (wave == 0) {
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          bq_m[(d * V + v) * 64 + lane] = qm[d][v];
+          bq_e[(d * V + v) * 64 + lane] = qe[d][v];
+        }
+    }
+    publish(1, zm, ze);
+  }
+  slice_epoch += (uint32_t)a.C;
+  bool alive = star_barrier(slice_counter, slice_epoch, a.error);
+  if (!alive && threadIdx.x == 0) (void)star_give_up(a.barrier, a.epoch0 + (uint32_t)nblocks);
+
+  // The root's scaled product P' (largest state 1) and its normaliser c_Q for this lane's
+  // observations, from the blocks' partial products of the iteration before.
+  fv<T, V> pf[D0];
+  fv<T, V> pf_sum;
+  double cq[V] = {0.0, 0.0};
+  auto combine = [&](int32_t buffer) {
+    const double* pm = a.part_mant + (size_t)buffer * a.C * D0 * a.npad;
+    const int32_t* pe = a.part_exp + (size_t)buffer * a.C * D0 * a.npad;
+    for (int32_t d = wave; d < D0; d += NW) {
+      double m[V] = {1.0, 1.0};
+      int32_t e[V] = {0, 0};
+      for (int32_t ch = 0; ch < a.C; ch += 16) {
+        double2 xm[16];
+        int2 xe[16];
+#pragma unroll
+        for (int32_t u = 0; u < 16; ++u) {
+          const bool live = ch + u < a.C;
+          const int64_t row = ((int64_t)(live ? ch + u : ch) * D0 + d) * a.npad + obs0;
+          xm[u] = make_double2(shared_load(pm + row), shared_load(pm + row + 1));
+          xe[u] = make_int2(shared_load(pe + row), shared_load(pe + row + 1));
+          if (!live) {
+            xm[u] = make_double2(1.0, 1.0);
+            xe[u] = make_int2(0, 0);
+          }
+        }
+#pragma unroll
+        for (int32_t u = 0; u < 16; ++u) {
+          m[0] *= xm[u].x;
+          m[1] *= xm[u].y;
+          e[0] += xe[u].x;
+          e[1] += xe[u].y;
+        }
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          m[v] = frexp(m[v], &de);
+          e[v] += de;
+        }
+      }
+      const double x = (double)prior[d];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        int de = 0;
+        m[v] = frexp(m[v] * x, &de);
+        e[v] = m[v] == 0.0 ? kDeadExponent : e[v] + de;
+        st_m[(d * V + v) * 64 + lane] = m[v];
+        st_e[(d * V + v) * 64 + lane] = e[v];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int32_t emax = kDeadExponent;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        const int32_t x = st_e[(d * V + v) * 64 + lane];
+        emax = x > emax ? x : emax;
+      }
+      double z = 0.0;
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        const double scaled = ldexp(st_m[(d * V + v) * 64 + lane], clamp_shift(st_e[(d * V + v) * 64 + lane] - emax));
+        z += scaled;
+        pf[d][v] = (T)scaled;
+      }
+      cq[v] = (double)(T)((double)emax * 0.6931471805599453 + log(z));
+    }
+    pf_sum = pf[0];
+#pragma unroll
+    for (int32_t d = 1; d < D0; ++d) pf_sum += pf[d];
+    __syncthreads();
+  };
+
+  // ---- iterations 2 .. T-1: the leaves' next normalisers from P', the block's partial product renewed
+  for (int32_t it = 2; it < a.iterations && alive; ++it) {
+    combine((it - 1) & 1);
+    double zm[V] = {1.0, 1.0};
+    int32_t ze[V] = {0, 0};
+    int32_t until = 4;
+    walk(true, [&](int32_t k, const fv<T, V>* ev, const fv<T, V>& zc) {
+      fv<T, V> q[D0];
+      family_q(k, ev, q);
+      fv<T, V> sum_r = splat<T, V>(0.f);
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) sum_r = __builtin_elementwise_fma(pf[d], rcpv<T, V>(q[d]), sum_r);
+      const fv<T, V> zn = pf_sum * rcpv<T, V>(sum_r);
+      *reinterpret_cast<fv<T, V>*>(zs + (int64_t)k * a.npad) = zn;
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) zm[v] *= (double)zc[v];
+      if (--until == 0 || sizeof(T) == 8) {
+        until = 4;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          zm[v] = frexp(zm[v], &de);
+          ze[v] += de;
+        }
+      }
+    });
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      zm[v] = frexp(zm[v], &de);
+      ze[v] += de;
+    }
+    publish(it, zm, ze);
+    slice_epoch += (uint32_t)a.C;
+    alive = star_barrier(slice_counter, slice_epoch, a.error);
+    if (!alive && threadIdx.x == 0) (void)star_give_up(a.barrier, a.epoch0 + (uint32_t)nblocks);
+  }
+
+  // ---- iteration T on the fly: log-likelihood and count sums
+  if (alive) {
+    combine((a.iterations - 1) & 1);
+    double zm[V] = {1.0, 1.0};
+    int32_t ze[V] = {0, 0};
+    int32_t until = 4;
+    walk(true, [&](int32_t k, const fv<T, V>* ev, const fv<T, V>& z) {
+      fv<T, V> q[D0], r[D0];
+      family_q(k, ev, q);
+      fv<T, V> inv_sum = splat<T, V>(0.f);
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        r[d] = pf[d] * rcpv<T, V>(q[d]);
+        inv_sum += r[d];
+      }
+      inv_sum = rcpv<T, V>(inv_sum);
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) zm[v] *= (double)z[v];
+      if (--until == 0 || sizeof(T) == 8) {
+        until = 4;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) {
+          int de = 0;
+          zm[v] = frexp(zm[v], &de);
+          ze[v] += de;
+        }
+      }
+      // counts: sum_n t[d] * o[j], t = r / sum r, o = ev / z (padding observations masked)
+      const fv<T, V> scale = recipv<T, V>(z) * inv_sum;
+      fv<T, V> o[S];
+#pragma unroll
+      for (int32_t j = 0; j < S; ++j) {
+        o[j] = ev[j] * scale;
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v)
+          if (obs0 + v >= a.N) o[j][v] = 0.f;
+      }
+      T per_lane[E];
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d)
+#pragma unroll
+        for (int32_t j = 0; j < S; ++j) {
+          T x = r[d][0] * o[j][0];
+#pragma unroll
+          for (int32_t v = 1; v < V; ++v) x = fma_t(r[d][v], o[j][v], x);
+          per_lane[d * S + j] = x;
+        }
+      WaveSums<T, E> sums;
+      sums.reduce(per_lane, lane);
+      if (lane < 4) {
+#pragma unroll
+        for (int32_t g = 0; g < WaveSums<T, E>::H2; ++g) {
+          const int32_t e = WaveSums<T, E>::entry(lane, g);
+          if (e < E) shared_store(a.count_part + ((int64_t)k * E + e) * a.nslices + sl, (double)sums.out[g]);
+        }
+      }
+    });
+    double mine = 0.0;
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      const double m = frexp(zm[v], &de);
+      if (obs0 + v < a.N) mine += (double)(ze[v] + de) * 0.6931471805599453 + log(m);
+    }
+    // root: its normaliser and its posterior, by the blocks of chunk 0 (one per slice), wave 0
+    if (c == 0 && wave == 0) {
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v)
+        if (obs0 + v < a.N) mine += cq[v];
+      double inv[V];
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v) {
+        double zsum = 0.0;
+#pragma unroll
+        for (int32_t d = 0; d < D0; ++d) zsum += (double)pf[d][v];
+        inv[v] = obs0 + v < a.N ? 1.0 / zsum : 0.0;
+      }
+#pragma unroll
+      for (int32_t d = 0; d < D0; ++d) {
+        double x = (double)pf[d][0] * inv[0] + (double)pf[d][1] * inv[1];
+#pragma unroll
+        for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        if (lane == 0) shared_store(a.root_part + (int64_t)sl * D0 + d, x);
+      }
+    }
+#pragma unroll
+    for (int32_t off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if (lane == 0) red[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double total = 0.0;
+#pragma unroll
+      for (int32_t w = 0; w < NW; ++w) total += red[w];
+      shared_store(a.ll_part + blockIdx.x, total);
+    }
+    alive = star_barrier(a.barrier, a.epoch0 + (uint32_t)nblocks, a.error);
+  }
+
+  // ---- M-step (EmBatchOptimizer._m_step, optimizers/em_batch_optimizer.py:70-84), or - the launch
+  // given up - the old parameters into the caller's buffer: every block takes a share of the rows
+  const int64_t rows = (int64_t)a.K * D0;
+  const int64_t per_block = (rows + nblocks - 1) / nblocks;
+  const int64_t row0 = (int64_t)blockIdx.x * per_block;
+  const int64_t row1 = row0 + per_block < rows ? row0 + per_block : rows;
+  if (!alive) {
+    if (a.new_cpts) {
+      for (int64_t i = row0 * S + threadIdx.x; i < row1 * S; i += 64 * NW) {
+        const int64_t off = a.cpt_off[i / E] + i % E;
+        a.new_cpts[off] = a.cpts[off];
+      }
+      if (blockIdx.x == 0 && threadIdx.x < D0) a.new_cpts[a.root_cpt_off + threadIdx.x] = a.cpts[a.root_cpt_off + threadIdx.x];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.ll_out = __builtin_nan("");
+    return;
+  }
+  {
+#pragma clang fp contract(off)
+  const double gamma = a.regularization, rate = a.learning_rate;
+  auto new_row = [&](int64_t off, int32_t len, const double* counts) {
+    double sum = 0.0;
+    for (int32_t j = 0; j < len; ++j) sum += counts[j];
+    const double uniform = 1.0 / (double)len;
+    for (int32_t j = 0; j < len; ++j) {
+      double x = counts[j] / sum;
+      if (gamma != 0.0) {
+        const double p = (1.0 - gamma) * x;
+        const double u = gamma * uniform;
+        x = p + u;
+      }
+      if (rate >= 0.0) {
+        const double old = (1.0 - rate) * (double)a.cpts[off + j];
+        const double fresh = rate * x;
+        x = old + fresh;
+      }
+      a.cpts[off + j] = (T)x;
+      if (a.new_cpts) a.new_cpts[off + j] = (T)x;
+    }
+  };
+  // a wave per row: the lanes fetch the slices' sums side by side, then add them up
+  for (int64_t row = row0 + wave; row < row1; row += NW) {
+    const int32_t k = (int32_t)(row / D0), d = (int32_t)(row % D0);
+    const int64_t off = a.cpt_off[k] + (int64_t)d * S;
+    double counts[S];
+#pragma unroll
+    for (int32_t j = 0; j < S; ++j) {
+      const double* src = a.count_part + ((int64_t)k * E + d * S + j) * a.nslices;
+      double x = 0.0;
+      for (int32_t s2 = lane; s2 < a.nslices; s2 += 64) x += shared_load(src + s2);
+#pragma unroll
+      for (int32_t o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+      counts[j] = x * (double)a.cpts[off + j];
+    }
+    if (lane == 0) new_row(off, S, counts);
+  }
+  if (blockIdx.x == 0) {
+    double mine = 0.0;
+    for (int32_t b = threadIdx.x; b < nblocks; b += 64 * NW) mine += shared_load(a.ll_part + b);
+#pragma unroll
+    for (int32_t off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    __syncthreads();  // red[] was read by thread 0 before the barrier
+    if (lane == 0) red[wave] = mine;
+    // the root's counts: wave w sums states w, w + 8, ..
+    for (int32_t d = wave; d < D0; d += NW) {
+      double x = 0.0;
+      for (int32_t s2 = lane; s2 < a.nslices; s2 += 64) x += shared_load(a.root_part + (int64_t)s2 * D0 + d);
+#pragma unroll
+      for (int32_t o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+      if (lane == 0) red[NW + d] = x;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       double counts[D0];

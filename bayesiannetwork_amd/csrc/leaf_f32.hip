@@ -5,4 +5,6 @@
 namespace bn {
 template int launch_leaf_family<float>(Plan&, FactorGroup&, FusedFamily&, WideNode&, WideNode*, float*, const float*, int32_t,
                                      int32_t, int32_t, hipStream_t, bool, int32_t);
+
+bool hard_family_possible(const Plan& p, const FactorGroup& g, const FusedFamily& fam) { return hard_family_fits(p, g, fam); }
 }  // namespace bn

@@ -63,12 +63,47 @@ def test_em_optimizers_on_gpu_reproduce_reference(name, deferred):
                          EmBatchOptimizerSettings(em["learning_rate"], em["num_epochs"], em["regularization"],
                                                   deferred_logging=deferred), logger).optimize(loader)
         last = 2 * em["num_epochs"] - 1
-    # float32: three EM steps compound the inference rounding (and the reference's own float32 noise)
-    tol = dict(rtol=1e-9, atol=1e-13) if fx.dtype == torch.float64 else dict(rtol=1e-4, atol=2e-7)
+    if fx.dtype == torch.float64:
+        for node in network.nodes:
+            np.testing.assert_allclose(node.cpt.cpu().numpy(), fx[f"em/step{last}/{node.name}"], err_msg=node.name,
+                                       rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose([log.ll for log in logger.logs], fx["em/ll"], rtol=1e-9)
+        return
+    # float32.  The yardstick is the reference's float64 run of the same optimisation (the sibling
+    # fixture: same network, same evidence, same settings), not its float32 run, which carries rounding
+    # of its own: the parameters after the last step must be within 1e-5 relative (the tolerance of the
+    # reference's own float32 assertions, common/testcase_extensions.py:7-14: five decimal places;
+    # 2e-7 absolute covers entries near zero) of that truth, on tree models and loopy ones alike
+    # (measured: 1.6e-7 on the trees, 4.2e-6 at worst on the loopy 16-pixel model, where the
+    # reference's own float32 run is 8e-6 off; gpurun_out/em_margins.json).
+    truth = Fixture(name[:-4] + "_f64")
+    for a, b in zip(fx.evidence_tensors(), truth.evidence_tensors()):
+        assert torch.equal(a.double(), b.double().float().double()), "the two fixtures describe different runs"
+    ours_worst, theirs_worst = 0.0, 0.0
     for node in network.nodes:
-        np.testing.assert_allclose(node.cpt.cpu().numpy(), fx[f"em/step{last}/{node.name}"], err_msg=node.name, **tol)
-    np.testing.assert_allclose([log.ll for log in logger.logs], fx["em/ll"],
-                               rtol=1e-9 if fx.dtype == torch.float64 else 1e-5)
+        want = truth[f"em/step{last}/{node.name}"].astype(np.float64)
+        ours = node.cpt.cpu().numpy().astype(np.float64)
+        theirs = fx[f"em/step{last}/{node.name}"].astype(np.float64)
+        scale = np.abs(want) + 2e-7 / 1e-5
+        ours_worst = max(ours_worst, float((np.abs(ours - want) / scale).max()))
+        theirs_worst = max(theirs_worst, float((np.abs(theirs - want) / scale).max()))
+    bound = 1e-5
+    _record_margin(name + ("/deferred" if deferred else ""), ours_worst, theirs_worst, bound)
+    assert ours_worst <= bound, (ours_worst, theirs_worst, bound)
+    np.testing.assert_allclose([log.ll for log in logger.logs], truth["em/ll"], rtol=1e-5)
+
+
+def _record_margin(key, ours, theirs, bound):
+    """gpurun_out/em_margins.json: per float32 EM fixture, the largest deviation (relative, with the
+    absolute floor folded in) of the engine's and of the reference's float32 parameters from the
+    reference's float64 ones, and the bound that was applied."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "em_margins.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = dict(ours=ours, reference_float32=theirs, bound=bound)
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
 
 @pytest.mark.parametrize("name", ["c3a_784_f32", "c3b_784_f32"])
@@ -128,6 +163,65 @@ def test_full_batch_size_properties(name):
                 theirs = np.abs(fx[f"out/counts/{node.name}"].astype(np.float64) - truth) / (np.abs(truth) + 1e-7)
                 rtol = max(2e-4, 2.0 * float(theirs.max()))
             np.testing.assert_allclose(sums.cpu().numpy(), fx[key], rtol=rtol, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,n", [("c2_docs2_f32", 1 << 20), ("c4_loops_f32", 1 << 20), ("deep tree", 131072)])
+def test_full_batch_size_properties_of_the_other_workloads(name, n):
+    """The docs network and the loops network at 2^20 observations and the depth-6 tree of 64-state
+    nodes at 131 072 (the sizes they are benchmarked at), made of a few hundred base rows repeated:
+    every copy reproduces the base row's marginals bit for bit, marginals are normalised, the
+    log-likelihood scales with the copies, the expected-count means are those of the base batch, and
+    (fixture networks) the base rows' marginals are the fixture's."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.torch_settings import TorchSettings
+
+    ts = TorchSettings(device="cuda", dtype="float32")
+    if name == "deep tree":
+        import os
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+
+        network, observed = bench.build_deep_tree(ts)
+        base = 256
+        rows = bench.one_hot_evidence(ts, base, observed, 5, "cuda").data
+        iterations, loops, fx = None, False, None
+        probes = [list(network.nodes)[0], list(network.nodes)[17], observed[3]]
+    else:
+        fx = Fixture(name)
+        network, observed, by_name = fx.build(ts)
+        rows = fx.evidence_tensors("cuda")
+        base = fx.meta["N"]
+        iterations, loops = fx.meta["num_iterations"], fx.meta["allow_loops"]
+        probes = list(network.nodes)
+    reps = n // base
+    n = base * reps
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations, allow_loops=loops)
+    small = HipSpaInferenceMachine(settings, network, observed, base)
+    small.enter_evidence(Evidence(rows, ts))
+    big = HipSpaInferenceMachine(settings, network, observed, n)
+    big.enter_evidence(Evidence([r.repeat(reps, 1).contiguous() for r in rows], ts))
+
+    for node, a, b in zip(probes, big.infer_single_nodes(probes), small.infer_single_nodes(probes)):
+        assert torch.equal(a.view(reps, base, -1), b.expand(reps, -1, -1)), f"replicated rows of {node.name} differ"
+        assert torch.allclose(a.sum(dim=1), torch.ones(n, device="cuda"), atol=2e-5)
+        if fx is not None:
+            np.testing.assert_allclose(b.cpu().numpy(), fx[f"truth/single/{node.name}"], rtol=4e-5 if loops else 1e-5,
+                                       atol=1e-7)
+    fam_big = big.infer_nodes_with_parents(probes[-1:])[0]
+    fam_small = small.infer_nodes_with_parents(probes[-1:])[0]
+    assert torch.equal(fam_big[:base], fam_small) and torch.equal(fam_big[n - base:], fam_small)
+    np.testing.assert_allclose(big.log_likelihood(), reps * small.log_likelihood(), rtol=1e-9)
+    counts_big = (big.expected_count_sums() / n).cpu().numpy()
+    counts_small = (small.expected_count_sums() / base).cpu().numpy()
+    np.testing.assert_allclose(counts_big, counts_small, rtol=2e-6, atol=1e-12)
+    # the one-call statistics route (what an EM step runs) on the big batch: the same numbers
+    again = HipSpaInferenceMachine(settings, network, observed, n)
+    ll, sums = again.em_statistics(Evidence([r.repeat(reps, 1).contiguous() for r in rows], ts))
+    np.testing.assert_allclose(ll.item(), reps * small.log_likelihood(), rtol=1e-7)
+    np.testing.assert_allclose((sums / n).cpu().numpy(), counts_small, rtol=4e-6, atol=1e-12)
 
 
 @pytest.mark.parametrize("name", ["c3a_784_f32", "c3a_mini16_f32", "c2_docs2_f32", "c3b_784_f32"])
@@ -367,7 +461,7 @@ def test_hard_evidence_fills_the_observation_slots_like_its_tensors(dtype, n):
 @pytest.mark.parametrize("deferred", [False, True])
 def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory(deferred):
     """Host-resident uint8 batches through PrefetchingLoader give the same EM trajectory as the same
-    evidence resident on the device as float tensors.  With deferred logging no step waits for the
+    state bytes resident on the device (bit for bit) and as the float tensors they stand for.  With deferred logging no step waits for the
     host, so a device batch is dropped while the kernels that read it may still be queued: the
     loader has to keep its memory from being reused by a later copy until they have run."""
     import copy
@@ -391,7 +485,7 @@ def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory(deferred)
     host_batches = [HardEvidence(torch.randint(0, 2, (30, n), generator=gen), [2] * 30, host, 0.9999995, 5e-7)
                     for _ in range(batches)]
     results = []
-    for mode in ("prefetched", "resident"):
+    for mode in ("prefetched", "resident states", "resident"):
         net, kids = build()
         logger = OptimizerLogger()
         opt = EmBatchOptimizer(
@@ -400,13 +494,22 @@ def test_prefetching_loader_feeds_the_batch_optimizer_from_host_memory(deferred)
                                      deferred_logging=deferred), logger)
         if mode == "prefetched":
             loader = PrefetchingLoader(host_batches, "cuda")
+        elif mode == "resident states":
+            loader = [HardEvidence(b.states.to("cuda"), b.num_states, ts, b.on_value, b.off_value) for b in host_batches]
         else:
             loader = [Evidence([d.to("cuda") for d in b.data], ts) for b in host_batches]
         opt.optimize(loader)
         results.append(([log.ll for log in logger.logs], [node.cpt.clone() for node in net.nodes]))
+    # prefetched or resident, the same state bytes take the same route: bit for bit
     assert results[0][0] == results[1][0]
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.equal(a, b)
+    # the state bytes are read in place with per-family tables, the float tensors multiplied out per
+    # observation: the same sums cut differently (2e-6 relative, as for a single step), over 8 / 24 steps
+    for ll_a, ll_b in zip(results[0][0], results[2][0]):
+        assert abs(ll_a - ll_b) <= 2e-6 * abs(ll_b)
+    for a, b in zip(results[0][1], results[2][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-6)
 
 
 def test_full_batch_em_never_lowers_the_likelihood_on_sampled_data():
@@ -602,18 +705,28 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
 
     one, separate = run(True), run(False)
     assert len(one) == len(separate)
+    # State bytes of a float32 plan whose families all sit under one wide parent are read in place by the
+    # one-call step (per-family tables, sums by evidence form: kernels_hard.h), and expanded by the
+    # separate calls: the same sums cut differently, 2e-6 relative per step as in the headline-model
+    # test, over six steps.  Every other combination launches the same kernels: bit for bit.
+    in_place = hard and name == "c3a_784_f32"
     for a, b in zip(one, separate):
-        assert torch.equal(a, b)
+        if in_place:
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), (a - b).abs().max()
+        else:
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("hard", [False, True])
-@pytest.mark.parametrize("n", [1, 64, 100, 129, 1000, 1024])
+@pytest.mark.parametrize("n", [1, 64, 100, 129, 1000, 1024, 1025, 2050, 2560, 3072])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("classes", [10, 7])
 def test_one_launch_star_step_agrees_with_one_launch_per_pass(classes, dtype, n, hard):
-    """The cooperative one-launch EM step of the 784-leaf model against the launch-per-pass route
-    (itself checked against the oracle above): log-likelihoods and parameters after each of four
-    steps, to rounding."""
+    """The one-launch EM step of the 784-leaf model against the launch-per-pass route (itself checked
+    against the oracle above): log-likelihoods and parameters after each of four steps, to
+    rounding.  Up to 1 024 observations the kernel that keeps the evidence in registers, above that
+    (to 3 072, where one launch per pass catches up) the one that streams it per iteration (16, 14,
+    12 and 10 chunks of families per slice; an odd and a ragged batch size)."""
     import bench
     from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
@@ -655,4 +768,7 @@ def test_one_launch_star_step_agrees_with_one_launch_per_pass(classes, dtype, n,
     for (ll_a, new_a), (ll_b, new_b) in zip(run(True), run(False)):
         assert torch.isfinite(ll_a).all()
         assert abs(ll_a.item() - ll_b.item()) <= tol * abs(ll_b.item())
-        np.testing.assert_allclose(new_a.cpu().double().numpy(), new_b.cpu().double().numpy(), rtol=10 * tol, atol=tol)
+        # parameters: 10 tol.  The root's posterior of the query (700 or 1000 values, each a normalised
+        # product of 784 factors) multiplies the parameters' rounding differences up: 50 tol
+        rtol = 10 * tol if new_a.numel() > n * classes else 50 * tol
+        np.testing.assert_allclose(new_a.cpu().double().numpy(), new_b.cpu().double().numpy(), rtol=rtol, atol=tol)

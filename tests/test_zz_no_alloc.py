@@ -110,7 +110,8 @@ def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
                     assert lib.bn_plan_map_message_arrays(machine._plan) == 0
                     assert machine.unmapped_bytes == 0
                 else:
-                    machine.reset_messages()
+                    machine.reset_messages()  # (forgets the evidence too)
+                    machine.enter_evidence(evidence)
             pair.append((machine,) + _statistics(entry, machine))
         (static_machine, ll_s, counts_s), (plain_machine, ll_p, counts_p) = pair
         assert np.isfinite(ll_s) and np.isfinite(counts_s).all()
@@ -127,6 +128,7 @@ def test_static_scratch_entry_point_equals_bn_em_statistics(dtype):
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     last.reset_messages()
+    last.enter_evidence(evidence)
     _statistics(lib.bn_em_statistics_static, last, warm=True)
     assert torch.cuda.mem_get_info()[0] == free_before
 
@@ -178,6 +180,7 @@ def test_static_scratch_entry_point_never_backs_the_lazy_message_arrays(dtype):
     assert static_machine.unmapped_bytes == lazy
     # after a reset the plan is as new: served again, still nothing backed
     static_machine.reset_messages()
+    static_machine.enter_evidence(evidence)
     ll_again, counts_again = _statistics(lib.bn_em_statistics_static, static_machine, warm=True)
     assert ll_again == ll_s and np.array_equal(counts_again, counts_s)
     assert static_machine.unmapped_bytes == lazy
