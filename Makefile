@@ -6,9 +6,20 @@ OUT   := bayesiannetwork_amd/libbn_hip.so
 OBJ   := build
 # -MMD: every object depends on exactly the headers it includes (build/*.d)
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Iinclude -MMD -MP
-OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/sampler.o $(OBJ)/plan.o
+OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/sampler.o $(OBJ)/plan.o $(OBJ)/packs.o
+# Cardinality packs built with the library (csrc/cardinality_pack.h): the fused kernels for wide parents
+# with these numbers of states.  One more:  make pack D0=14
+PACKS ?= 11 13 24 32
+PACK_OUT = bayesiannetwork_amd/libbn_hip_d$(1).so
 
-all: $(OUT)
+all: $(OUT) packs
+
+packs: $(foreach d,$(PACKS),$(call PACK_OUT,$(d)))
+
+pack: $(call PACK_OUT,$(D0))
+
+bayesiannetwork_amd/libbn_hip_d%.so: $(SRC)/pack.hip $(wildcard $(SRC)/*.h)
+	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -DBN_PACK_D0=$* -shared -Wl,-z,defs -o $@ $<
 
 $(OUT): $(OBJS)
 	$(HIPCC) -fPIC --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
@@ -30,6 +41,6 @@ examples/c_abi_demo: examples/c_abi_demo.cpp $(OUT) include/bn_hip.h
 -include $(OBJS:.o=.d)
 
 clean:
-	rm -rf $(OUT) $(OBJ) examples/c_abi_demo
+	rm -rf $(OUT) $(OBJ) examples/c_abi_demo bayesiannetwork_amd/libbn_hip_d*.so
 
-.PHONY: all clean demo
+.PHONY: all clean demo packs pack

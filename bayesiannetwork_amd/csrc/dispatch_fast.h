@@ -5,6 +5,7 @@
 #pragma once
 
 #include "launch.h"
+#include "cardinality_pack.h"
 #include "fast_state.h"
 #include "kernels_leaf.h"
 #include <algorithm>
@@ -34,7 +35,8 @@ inline bool small_dim(int32_t d) {
   return false;
 }
 
-inline bool parent_dim(int32_t d) {
+// cardinalities of a wide parent whose kernels are part of the library proper ...
+inline bool builtin_parent_dim(int32_t d) {
   switch (d) {
 #define X(V) \
   case V:    \
@@ -44,6 +46,8 @@ inline bool parent_dim(int32_t d) {
   }
   return false;
 }
+// ... and all that can be served: those, and any with a cardinality pack next to the library
+inline bool parent_dim(int32_t d) { return builtin_parent_dim(d) || cardinality_pack(d) != nullptr; }
 
 inline bool is_wide_group(const Plan& p, const VariableGroup& g) {
   return g.num_inputs > kWideFanIn && parent_dim(g.num_states);
@@ -670,9 +674,46 @@ inline WideArgs wide_args(const Plan& p, const VariableGroup& g, const WideNode&
   return a;
 }
 
+// The wide node's kernels for S states as addresses (all of them take (arena, WideArgs))
 template <typename T, int S>
+inline WideKernelRefs wide_kernels_for() {
+  WideKernelRefs k{};
+  if constexpr (std::is_same<T, float>::value) {
+    k.product = reinterpret_cast<const void*>(&wide_product_fast<S>);
+    k.emit = reinterpret_cast<const void*>(&wide_emit_fast<S>);
+  } else {
+    k.product = reinterpret_cast<const void*>(&wide_product_any<T, S>);
+  }
+  if constexpr (S <= 16) {  // (one wave per state: a block of 64 * S threads)
+    k.combine_states = reinterpret_cast<const void*>(&wide_combine_states<T, S>);
+    k.combine_states_lds = [](int32_t n) -> size_t { return combine_states_lds_bytes<S>(n); };
+  }
+  k.combine_fast = reinterpret_cast<const void*>(&wide_combine_fast<T, S>);
+  k.combine_lds = [](int32_t nw) -> size_t { return combine_lds_bytes<S>(nw); };
+  return k;
+}
+
+template <typename T>
+inline WideKernelRefs wide_kernels(int32_t states) {
+  switch (states) {
+#define X(SV) \
+  case SV:    \
+    return wide_kernels_for<T, SV>();
+    BN_PARENT_DIMS(X)
+#undef X
+  }
+  if (const CardinalityPack* pack = cardinality_pack(states)) return pack->wide(std::is_same<T, float>::value ? 0 : 1);
+  return WideKernelRefs{};
+}
+
+template <typename T>
 inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w, T* arena, int32_t fresh,
                              hipStream_t s, bool next_folds = false) {
+  using WideFn = void (*)(T*, WideArgs);
+  using WideReadFn = void (*)(const T*, WideArgs);
+  const int32_t S = g.num_states;
+  const WideKernelRefs k = wide_kernels<T>(S);
+  if (!k.combine_fast) return false;
   if (w.combined_ahead) {  // the previous iteration's launch did this combine too
     w.combined_ahead = false;
     return true;
@@ -713,40 +754,32 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
              w.zdiv_mant[0], w.zdiv_exp[0], zd);
       if (!launch_ok()) return false;
     }
-    if constexpr (std::is_same<T, float>::value) {
-      launch(wide_product_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
-      if (!launch_ok()) return false;
-    } else {
-      launch(wide_product_any<T, S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles * leaf_parts(p))), dim3(256), 0, s,
-             arena, a);
-      if (!launch_ok()) return false;
-    }
+    // (the float kernel moves 16 bytes per lane: one wave per chunk and tile)
+    const int64_t waves = (int64_t)w.chunks * p.ntiles * (std::is_same<T, float>::value ? 1 : leaf_parts(p));
+    launch(reinterpret_cast<WideReadFn>(const_cast<void*>(k.product)), dim3(wave_blocks(waves)), dim3(256), 0, s, arena, a);
+    if (!launch_ok()) return false;
   }
   // (large batches that also store the product over the chunks: measured 22 against 27 us at 60 000
   // observations on the kernel with one observation per lane and a wave per four chunks)
   const bool states_kernel = a.prod_mode == 1 ? p.ntiles < 64 : a.prod_mode != 2;
   // (one wave per state: a block of 64 * S threads, so up to 16 states)
-  if (S <= 16 && !fresh && states_kernel && p.ntiles <= env_combine_states_max() &&
+  if (k.combine_states && !fresh && states_kernel && p.ntiles <= env_combine_states_max() &&
       (int32_t)w.uncovered.size() <= kMaxUncovered) {
     // a handful of blocks: the launch lasts as long as its longest chain, so one wave per state
-    if constexpr (S <= 16) {
-      const size_t lds = combine_states_lds_bytes<S>(a.n_uncovered);
-      if (lds > 48 * 1024 &&
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_states<T, S>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return false;
-      launch(wide_combine_states<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
-    }
+    const size_t lds = k.combine_states_lds(a.n_uncovered);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(k.combine_states, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;
+    launch(reinterpret_cast<WideFn>(const_cast<void*>(k.combine_states)), dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * S), lds, s, arena, a);
   } else {
     // waves per block: one per group of four chunks, none to spare while the messages are fresh
     int32_t nw = (fresh || a.prod_mode == 2) ? 1 : std::max(1, std::min(kCombineMaxWaves, (w.chunks + 3) / 4));
-    while (nw > 1 && combine_lds_bytes<S>(nw) > 128 * 1024) --nw;  // (a wave then takes more of the chunks)
-    const size_t lds = combine_lds_bytes<S>(nw);
+    while (nw > 1 && k.combine_lds(nw) > 128 * 1024) --nw;  // (a wave then takes more of the chunks)
+    const size_t lds = k.combine_lds(nw);
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_combine_fast<T, S>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute(k.combine_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return false;
-    launch(wide_combine_fast<T, S>, dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw), lds, s, arena, a);
+    launch(reinterpret_cast<WideFn>(const_cast<void*>(k.combine_fast)), dim3((uint32_t)(p.ntiles * (p.tile / 64))), dim3(64 * nw), lds, s, arena, a);
   }
   if (!launch_ok()) return false;
   if (a.prod_mode == 1) w.products_cached = true;
@@ -758,12 +791,9 @@ inline bool launch_wide_node(const Plan& p, const VariableGroup& g, WideNode& w,
     if (!fresh && w.zdiv_mant[0]) w.zd_read ^= 1;
   }
   if (!fused) {
-    if constexpr (std::is_same<T, float>::value) {
-      launch(wide_emit_fast<S>, dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
-      if (!launch_ok()) return false;
-    } else {
-      return false;
-    }
+    if (!k.emit) return false;
+    launch(reinterpret_cast<WideFn>(const_cast<void*>(k.emit)), dim3(wave_blocks((int64_t)w.chunks * p.ntiles)), dim3(256), 0, s, arena, a);
+    if (!launch_ok()) return false;
   }
   return true;
 }
@@ -855,16 +885,7 @@ int launch_variable_fast(Plan& p, VariableGroup& g, T* arena_t, int32_t fresh, h
       bool next_folds = last_but_one_before_reduce && !w.fused_fgroups.empty();
       for (int32_t fi : w.fused_fgroups)
         next_folds = next_folds && leaf_launch_folds(st->fused[fi], true, 2, fresh, first_iteration);
-      bool ok = false;
-      switch (g.num_states) {
-#define X(SV)                                                               \
-  case SV:                                                                  \
-    ok = launch_wide_node<T, SV>(p, g, w, arena_t, fresh, s, next_folds);   \
-    break;
-        BN_PARENT_DIMS(X)
-#undef X
-      }
-      if (!ok) return -1;
+      if (!launch_wide_node<T>(p, g, w, arena_t, fresh, s, next_folds)) return -1;
     }
     return 1;
   }

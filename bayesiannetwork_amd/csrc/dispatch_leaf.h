@@ -5,6 +5,7 @@
 
 #include <algorithm>
 
+#include "cardinality_pack.h"
 #include "fast_state.h"
 #include "kernels_leaf.h"
 #include "kernels_hard.h"
@@ -15,6 +16,24 @@ namespace bn {
 
 template <typename T>
 using LeafFamilyFn = void (*)(T*, const T*, LeafFamilyArgs<T>);
+
+// The instantiations launch_leaf_family chooses from, per parent cardinality (a cardinality pack
+// holds the same ones): MODE = mode + 3 * state of leaf_family_p1; (OUT, FROM) of leaf_loop_p1;
+// MODE of the reduce launches with four observations per lane
+#define BN_FAMILY_MODES(X) X(1) X(2) X(4) X(5) X(7) X(8) X(10) X(11)
+#define BN_LOOP_COMBOS(X)                                                                        \
+  X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)            \
+  X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates) X(kLoopLight, kLoopIngestKeep)    \
+  X(kLoopLight, kLoopChunkCaller)                                                                \
+  X(kLoopLast, kLoopChunk) X(kLoopLast, kLoopFresh) X(kLoopLast, kLoopFromArrays)
+#define BN_PAIRS4_MODES(X)                                                                   \
+  X(kLeafReduce + 3 * kLeafSteady) X(kLeafReduce + 3 * kLeafFresh) X(kLeafReduce + 3 * kLeafFromArrays) \
+  X(kLeafReduce + 3 * kLeafRecompute) X(kLeafReduce + 3 * kLeafRecompute + kLeafCaller)
+
+template <typename T>
+constexpr int32_t pack_dtype() {
+  return std::is_same<T, float>::value ? 0 : 1;
+}
 
 template <typename T, int D0, int MODE>
 inline LeafFamilyFn<T> leaf_family_for_s(int32_t s) {
@@ -66,6 +85,10 @@ inline LeafLoopKernel<T> leaf_loop_lookup(int32_t d0, int32_t s, bool split) {
     BN_PARENT_DIMS(X)
 #undef X
   }
+  if (const CardinalityPack* pack = cardinality_pack(d0)) {
+    const LeafLoopRef r = pack->leaf_loop(pack_dtype<T>(), OUT, STATE, s, split ? 1 : 0);
+    return {reinterpret_cast<LeafFamilyFn<T>>(const_cast<void*>(r.fn)), r.lds_bytes};
+  }
   return {};
 }
 
@@ -79,6 +102,8 @@ inline LeafFamilyFn<T> leaf_family_lookup_pairs4(int32_t d0) {
     BN_PARENT_DIMS(X)
 #undef X
   }
+  if (const CardinalityPack* pack = cardinality_pack(d0))
+    return reinterpret_cast<LeafFamilyFn<T>>(const_cast<void*>(pack->leaf_family_pairs4(MODE)));
   return nullptr;
 }
 
@@ -91,6 +116,8 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
     BN_PARENT_DIMS(X)
 #undef X
   }
+  if (const CardinalityPack* pack = cardinality_pack(d0))
+    return reinterpret_cast<LeafFamilyFn<T>>(const_cast<void*>(pack->leaf_family(pack_dtype<T>(), MODE, s)));
   return nullptr;
 }
 
@@ -127,6 +154,12 @@ inline HardKernels hard_kernels(int32_t d0) {
     return hard_kernels_for<DV>();
     BN_PARENT_DIMS(X)
 #undef X
+  }
+  if (const CardinalityPack* pack = cardinality_pack(d0)) {
+    const HardKernelRefs r = pack->hard();
+    return {reinterpret_cast<HardFn>(const_cast<void*>(r.first)), reinterpret_cast<HardFn>(const_cast<void*>(r.light)),
+            reinterpret_cast<HardFn>(const_cast<void*>(r.reduce)), reinterpret_cast<HardTablesFn>(const_cast<void*>(r.tables)),
+            r.first_lds, r.rows_lds};
   }
   return {};
 }
@@ -286,10 +319,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   case OUT * 8 + FROM:                                                    \
     k = leaf_loop_lookup<T, OUT, FROM>(g.dims[0], g.dims[1], split); \
     break;
-      X(kLoopLight, kLoopChunk) X(kLoopLight, kLoopFresh) X(kLoopLight, kLoopFromArrays)
-      X(kLoopLight, kLoopIngest) X(kLoopLight, kLoopIngestStates) X(kLoopLight, kLoopIngestKeep)
-      X(kLoopLight, kLoopChunkCaller)
-      X(kLoopLast, kLoopChunk) X(kLoopLast, kLoopFresh) X(kLoopLast, kLoopFromArrays)
+      BN_LOOP_COMBOS(X)
 #undef X
     }
     fn = k.fn;
@@ -316,7 +346,7 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
   case M:    \
     fn = leaf_family_lookup<T, M>(g.dims[0], g.dims[1]); \
     break;
-      X(1) X(2) X(4) X(5) X(7) X(8) X(10) X(11)
+      BN_FAMILY_MODES(X)
 #undef X
     }
   }

@@ -1,0 +1,55 @@
+// Finds and loads cardinality packs (cardinality_pack.h).
+#include "cardinality_pack.h"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace bn {
+
+namespace {
+
+std::string library_directory() {
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&cardinality_pack_directory), &info) == 0 || !info.dli_fname) return ".";
+  const std::string path = info.dli_fname;
+  const size_t cut = path.find_last_of('/');
+  return cut == std::string::npos ? "." : path.substr(0, cut);
+}
+
+const CardinalityPack* load_pack(int32_t d0) {
+  if (getenv("BN_NO_PACKS")) return nullptr;
+  const std::string path = library_directory() + "/libbn_hip_d" + std::to_string(d0) + ".so";
+  void* handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!handle) return nullptr;
+  using Entry = const CardinalityPack* (*)();
+  Entry entry = reinterpret_cast<Entry>(dlsym(handle, "bn_cardinality_pack"));
+  const CardinalityPack* pack = entry ? entry() : nullptr;
+  if (!pack || pack->abi != kPackAbi || pack->d0 != d0) {
+    dlclose(handle);  // built for another version of the library
+    return nullptr;
+  }
+  return pack;
+}
+
+}  // namespace
+
+const char* cardinality_pack_directory() {
+  static const std::string dir = library_directory();
+  return dir.c_str();
+}
+
+const CardinalityPack* cardinality_pack(int32_t d0) {
+  static std::mutex lock;
+  static std::map<int32_t, const CardinalityPack*> known;
+  if (d0 < 2 || d0 > 64) return nullptr;
+  std::lock_guard<std::mutex> guard(lock);
+  auto it = known.find(d0);
+  if (it == known.end()) it = known.emplace(d0, load_pack(d0)).first;
+  return it->second;
+}
+
+}  // namespace bn

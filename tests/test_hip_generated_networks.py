@@ -110,8 +110,9 @@ CASES = {
     "many_state_tree": _many_state_tree,
     "two_wide_parents": _deep_chain_with_wide_node,
 }
-CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 12, 15, 16, 20)})
-CASES.update({f"wide_parent_{classes}_of_inner_nodes": _wide_parent_of_inner_nodes(classes) for classes in (7, 10, 15, 16, 20)})
+# (11, 13, 24, 32: cardinalities served by a cardinality pack, a shared object of its own per cardinality)
+CASES.update({f"wide_tree_{classes}_classes": _wide_tree_of(classes) for classes in (6, 7, 8, 9, 11, 12, 13, 15, 16, 20, 24, 32)})
+CASES.update({f"wide_parent_{classes}_of_inner_nodes": _wide_parent_of_inner_nodes(classes) for classes in (7, 10, 13, 15, 16, 20, 24)})
 CASES.update({f"two_parent_{d0}x{d1}x{s}": _two_parent_shape(d0, d1, s) for d0, d1, s in TWO_PARENT_SHAPES})
 
 
@@ -216,7 +217,8 @@ def test_generated_network_matches_oracle(name, dtype, n):
 
 @pytest.mark.parametrize("n", [10_000, 60_000])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents", "wide_tree_7_classes", "wide_tree_16_classes"])
+@pytest.mark.parametrize("name", ["wide_tree_partly_observed", "two_wide_parents", "wide_tree_7_classes", "wide_tree_16_classes",
+                                  "wide_tree_11_classes", "wide_tree_32_classes"])
 def test_several_fused_groups_at_large_batches(name, dtype, n):
     """Plans with more than one fused leaf-family group share the partial-sum slots of the
     log-likelihood reduction; at these batch sizes one group alone could fill all of them.  The
@@ -295,7 +297,7 @@ def test_two_parent_shapes_run_on_the_fused_kernel(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("classes", [6, 7, 8, 9, 12, 15, 16, 20])
+@pytest.mark.parametrize("classes", [6, 7, 8, 9, 11, 12, 13, 15, 16, 20, 24, 32])
 def test_every_parent_cardinality_up_to_ten_runs_on_the_fused_kernels(classes, dtype):
     from bayesiannetwork_amd.inference_machines.evidence import Evidence
     from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings

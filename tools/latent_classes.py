@@ -57,7 +57,9 @@ def run(classes, n=60000, leaves=784, steps=20):
     enable_profiling(False)
     fused = any(r["kernel"].startswith(f"leaf_family[{classes}x2") for r in report)
     return {"classes": classes, "fused": fused, "ms_per_step": ms, "samples_per_s": n / ms * 1e3,
-            "launches": sum(r["launches"] for r in report)}
+            "launches": sum(r["launches"] for r in report),
+            "kernels": sorted(({"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["total_ms"], 4)}
+                               for r in report), key=lambda r: -r["ms"])[:6]}
 
 
 if __name__ == "__main__":
