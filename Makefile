@@ -9,7 +9,7 @@ FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function 
 OBJS  := $(OBJ)/api.o $(OBJ)/leaf_f32.o $(OBJ)/leaf_f64.o $(OBJ)/exact.o $(OBJ)/sampler.o $(OBJ)/plan.o $(OBJ)/packs.o
 # Cardinality packs built with the library (csrc/cardinality_pack.h): the fused kernels for wide parents
 # with these numbers of states.  One more:  make pack D0=14
-PACKS ?= 11 13 24 32
+PACKS ?= 6 7 8 9 11 12 13 15 16 20 24 32
 PACK_OUT = bayesiannetwork_amd/libbn_hip_d$(1).so
 
 all: $(OUT) packs

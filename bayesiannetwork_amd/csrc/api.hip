@@ -1024,8 +1024,8 @@ bool finish_shape_ok(bn_plan* plan) {
   if (!p.parents[w.node].empty()) return false;
   const bn::FactorGroup& rg = p.fgroups[p.fgroup_of[w.node]];
   if (rg.dims.size() != 1 || rg.nodes.size() != 1 || fs->n_unfused_entries != rg.dims[0]) return false;
-  // (the root's sums are taken in the order of the specialised count kernel: only where that one serves the root)
-  if (!bn::em_root_lookup<float>(rg.dims[0])) return false;
+  // (the root's sums are taken in the order of the count kernels for parentless nodes, em_p1_fast /
+  // em_root_any, which serve any root of that many states)
   if (hipMalloc(reinterpret_cast<void**>(&plan->finish_counter), sizeof(uint32_t)) != hipSuccess ||
       hipMemset(plan->finish_counter, 0, sizeof(uint32_t)) != hipSuccess) {
     (void)hipGetLastError();
@@ -1395,6 +1395,13 @@ int64_t bn_plan_star_step_failures(const bn_plan* plan) {
 }
 
 int32_t bn_star_barrier_verdict(uint32_t seen, uint32_t target) { return bn::star_verdict(seen, target); }
+
+int32_t bn_cardinality_served(int32_t states) {
+  if (bn::builtin_parent_dim(states)) return 1;
+  return bn::cardinality_pack(states) ? 2 : 0;
+}
+
+const char* bn_cardinality_pack_directory(void) { return bn::cardinality_pack_directory(); }
 
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");

@@ -1201,6 +1201,11 @@ int launch_em_fast(Plan& p, FactorGroup& g, const T* arena, int32_t nchunks, dou
   EmFn<T> fn = nullptr;
   if (g.dims.size() == 1) {
     fn = em_root_lookup<T>(g.dims[0]);
+    if (!fn) {  // any other number of states
+      launch(em_root_any<T>, dim3(blocks), dim3(256), 0, s, arena, g.d_in, g.d_cpt, K, p.N, p.ntiles, nchunks, partial,
+             g.dims[0]);
+      return launch_ok() ? 1 : -1;
+    }
   } else if (g.dims.size() == 2) {
     const int32_t d0 = g.dims[0], sv = g.dims[1];
     if constexpr (std::is_same<T, float>::value) {

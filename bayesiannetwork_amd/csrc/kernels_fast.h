@@ -465,6 +465,47 @@ __global__ void __launch_bounds__(256) em_p1_fast(const T* __restrict__ arena, c
     }
 }
 
+// The count sums of parentless nodes with any number of states: em_p1_fast<T, 1, S, false> with S at
+// run time.  The same per-lane running sums in the same order (so the two agree bit for bit), four
+// states at a time (their loads are in flight together; the node's rows are read once in all).
+template <typename T>
+__global__ void __launch_bounds__(256) em_root_any(const T* __restrict__ arena, const int64_t* __restrict__ in_off,
+                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
+                                                  int64_t ntiles, int32_t nchunks, double* __restrict__ partial, int32_t S) {
+  const int32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (w >= (int64_t)K * nchunks) return;
+  const int32_t k = (int32_t)(w / nchunks);
+  const int32_t chunk = (int32_t)(w % nchunks);
+  const T* in_own = arena + in_off[k];
+  const int64_t per = (ntiles + nchunks - 1) / nchunks;
+  const int64_t t0 = chunk * per;
+  const int64_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  for (int32_t j0 = 0; j0 < S; j0 += 4) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t t = t0; t < t1; ++t) {
+      rowv<T> row[4];
+#pragma unroll
+      for (int32_t u = 0; u < 4; ++u) row[u] = loadw<T>(in_own, t * S + (j0 + u < S ? j0 + u : j0), lane);
+      const int64_t n0 = t * tile_of<T>::value + lane * rowv<T>::W;
+#pragma unroll
+      for (int32_t u = 0; u < 4; ++u)
+#pragma unroll
+        for (int32_t v = 0; v < rowv<T>::W; ++v) {
+          const double live = (n0 + v < N) ? 1.0 : 0.0;
+          acc[u] = fma(1.0 * live, (double)row[u].v[v], acc[u]);
+        }
+    }
+#pragma unroll
+    for (int32_t u = 0; u < 4; ++u) {
+      double x = acc[u];
+#pragma unroll
+      for (int32_t off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (lane == 0 && j0 + u < S) partial[(cpt_off[k] + j0 + u) * nchunks + chunk] = x;
+    }
+  }
+}
+
 template <typename T, int D0, int D1, int S>
 __global__ void __launch_bounds__(256) em_p2_fast(const T* __restrict__ arena, const int64_t* __restrict__ in_off,
                                                  const int64_t* __restrict__ cpt_off, int32_t K, int64_t N,
@@ -532,8 +573,9 @@ __global__ void __launch_bounds__(256) em_p2_fast(const T* __restrict__ arena, c
 // =================================================================================
 
 #define BN_SMALL_DIMS(X) X(2) X(3) X(4) X(5) X(10)
-// cardinalities of a wide parent (the D0 of the leaf-family kernels, the S of the wide-node kernels)
-#define BN_PARENT_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) X(15) X(16) X(20)
+// cardinalities of a wide parent (the D0 of the leaf-family kernels, the S of the wide-node kernels) whose
+// instantiations are part of the library; any other is served by a cardinality pack (cardinality_pack.h)
+#define BN_PARENT_DIMS(X) X(2) X(3) X(4) X(5) X(10)
 // root cardinalities of the one-launch EM step of small star networks (kernels_star.h)
 #define BN_STAR_DIMS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 // (D0, D1, S) of the leaf families with two wide parents that have a fused kernel (CPT [D0][D1][S])

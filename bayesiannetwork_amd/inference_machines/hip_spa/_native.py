@@ -65,6 +65,10 @@ def _declare(lib):
     lib.bn_plan_star_step_failures.argtypes = [c_void_p]
     lib.bn_star_barrier_verdict.restype = c_int32
     lib.bn_star_barrier_verdict.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.bn_cardinality_served.restype = c_int32
+    lib.bn_cardinality_served.argtypes = [c_int32]
+    lib.bn_cardinality_pack_directory.restype = ctypes.c_char_p
+    lib.bn_cardinality_pack_directory.argtypes = []
     lib.bn_plan_step_graph_launches.restype = c_int64
     lib.bn_plan_step_graph_launches.argtypes = [c_void_p]
     lib.bn_set_cpts.restype = c_int
@@ -139,7 +143,7 @@ def _declare(lib):
 EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_plan_unmapped_bytes", "bn_plan_map_message_arrays", "bn_plan_enable_step_graphs",
-    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_star_step_launches", "bn_plan_star_step_failures", "bn_star_barrier_verdict", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
+    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_star_step_launches", "bn_plan_star_step_failures", "bn_star_barrier_verdict", "bn_cardinality_served", "bn_cardinality_pack_directory", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_static", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",
@@ -165,6 +169,20 @@ def load():
             raise ImportError(f"libbn_hip.so ABI {lib.bn_abi_version()} != expected {ABI_VERSION}; rebuild it")
         _lib = lib
     return _lib
+
+
+def build_cardinality_pack(states: int) -> str:
+    """Builds the cardinality pack for wide parents of ``states`` states (``make pack D0=states`` in
+    the source tree: about a minute of hipcc, no GPU needed) unless it is there already, and returns
+    its path.  Set-up code calls this before the first plan with such a node is built; plans built
+    earlier keep the route they have.  The library itself never compiles anything."""
+    import subprocess
+
+    path = os.path.join(os.path.dirname(_LIB_PATH), f"libbn_hip_d{int(states)}.so")
+    if not os.path.exists(path):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(_LIB_PATH)))
+        subprocess.run(["make", "-C", root, "pack", f"D0={int(states)}"], check=True, capture_output=True)
+    return path
 
 
 def check(rc: int):

@@ -148,6 +148,21 @@ int64_t bn_plan_star_step_failures(const bn_plan* plan);
 int32_t bn_star_barrier_verdict(uint32_t seen, uint32_t target);
 
 /*
+ * Which wide-parent cardinalities run on the fused kernels?  Those kernels keep a parent's states in
+ * registers, so every number of states is an instantiation of its own: a fixed list is part of the
+ * library, and any other is served by a "cardinality pack", libbn_hip_d<states>.so next to the
+ * library (built by `make pack D0=<states>` from the same sources; the packs of the Makefile's PACKS
+ * list are built with the library), loaded the first time a plan needs it.  Without either, a node
+ * with many children and that many states runs on the unfused kernels (correct, and some hundred
+ * times slower at 784 children).  Returns 1 = part of the library, 2 = a pack is present (this loads
+ * it), 0 = neither.  Host-only, needs no GPU.  (Has no counterpart in the reference, which treats
+ * every shape alike: spa_v3/factor_graph.py:339-395.)
+ */
+int32_t bn_cardinality_served(int32_t states);
+/* The directory the library looks for packs in (its own). */
+const char* bn_cardinality_pack_directory(void);
+
+/*
  * Snapshot the CPTs (device pointer to the flat CPT buffer, plan dtype).
  * Replaces torch.stack(node.cpt ...) in FactorNodeGroup.__init__
  * (spa_v3/factor_graph.py:192).

@@ -243,3 +243,31 @@ def test_barrier_verdict_of_the_one_launch_step():
             assert lib.bn_star_barrier_verdict((target + arrived + poison) & 0xFFFFFFFF, target) == void
     # a poisoned counter stays void for the epochs of later launches too (they abort at once)
     assert lib.bn_star_barrier_verdict((1000 + poison) & 0xFFFFFFFF, 1000 + 16 * 128) == void
+
+
+def test_cardinality_packs_are_found_next_to_the_library():
+    """Wide-parent cardinalities: a fixed list is part of the library, the Makefile's PACKS are shared
+    objects of their own next to it (loaded here, on the CPU: a pack holds kernels and tables, and
+    loading one launches nothing), and anything else is reported as not served.  Every pack exports
+    the one entry point the library binds and answers for the cardinality in its name."""
+    import ctypes
+    import glob
+    import os
+    import re
+
+    lib = _native.load()
+    directory = lib.bn_cardinality_pack_directory().decode()
+    assert os.path.samefile(directory, os.path.dirname(_native._LIB_PATH))
+    for states in (2, 3, 4, 5, 10):
+        assert lib.bn_cardinality_served(states) == 1
+    packs = sorted(glob.glob(os.path.join(directory, "libbn_hip_d*.so")))
+    assert len(packs) >= 4, "make all builds the packs of the Makefile's PACKS list"
+    for path in packs:
+        states = int(re.search(r"_d(\d+)\.so$", path).group(1))
+        assert lib.bn_cardinality_served(states) == 2, path
+        pack = ctypes.CDLL(path)
+        pack.bn_cardinality_pack.restype = ctypes.POINTER(ctypes.c_int32)
+        table = pack.bn_cardinality_pack()
+        assert table[1] == states  # {abi, d0, ...}
+    for states in (1, 0, -3, 47, 65, 1000):
+        assert lib.bn_cardinality_served(states) == 0
