@@ -49,7 +49,10 @@ FP32_PEAK_TFLOPS = 157.3  # vector and matrix fp32 alike
 
 # profile label -> kernel-name stems it covers (a label can stand for several kernels: the loop launches of
 # the leaf families run on leaf_loop_p1, their full / reduce launches on leaf_family_p1)
-_KERNEL_STEMS = {"leaf_family": ("bn::leaf_family_p", "bn::leaf_loop_p"), "factor_pass": ("bn::factor_p",),
+_KERNEL_STEMS = {"leaf_family": ("bn::leaf_family_p", "bn::leaf_loop_p", "bn::hard_loop_", "bn::hard_reduce_"),
+                 "tree_iteration": ("bn::factor_tree_mfma",), "tree_iteration_fresh": ("bn::factor_tree_mfma",),
+                 "tree_iteration_exact": ("bn::factor_tree_mfma",), "em_finish": ("bn::em_finish",),
+                 "factor_pass": ("bn::factor_p",),
                  "em_counts": ("bn::em_p",), "variable_pass": ("bn::variable_small_fast",),
                  "wide_combine": ("bn::wide_combine_fast", "bn::wide_combine_states"),
                  "evidence_scatter": ("bn::evidence_scatter",), "log_likelihood": ("bn::ll_partial",)}
@@ -78,7 +81,7 @@ def pmc_counters(kernel_label: str, model: str, signature: str):
     has changed since the pass and the figure is None.  A label can cover several instantiations
     (loop / reduce modes): the launch-weighted mean."""
     stems = _KERNEL_STEMS.get(kernel_label.split("[")[0])
-    tag = "" if model == "c3a" else f"_{model}"
+    tag = "" if model == "c3a" else f"_{model}"  # (model "c3a_u8": the headline model on resident state bytes)
     out, provenance = [], {}
     for suffix, key in ((f"pmc_traffic{tag}.json", "hbm_bytes_per_launch"), (f"pmc_valu{tag}.json", "valu_busy")):
         path = _latest_profile(suffix)
@@ -551,8 +554,10 @@ def main():
         primary = strong if (args.scaling == "strong" and strong is not None) else weak
         n = primary["n"]
         # the committed counter passes ran the default command: float32, 60 000 resident observations
-        default_workload = (args.dtype == "float32" and args.evidence == "resident" and n == (131072 if args.model == "c5" else 60000))
-        roofline = roofline_block(primary["timed"], args.model, default_workload) if primary["timed"] else None
+        default_workload = (args.dtype == "float32" and args.evidence in ("resident", "resident-uint8") and
+                            n == (131072 if args.model == "c5" else 60000))
+        counters_of = args.model + ("_u8" if args.evidence == "resident-uint8" else "")
+        roofline = roofline_block(primary["timed"], counters_of, default_workload) if primary["timed"] else None
         kernels = primary["kernels"]
 
         def figure(m):

@@ -1,7 +1,8 @@
 """Secondary measurements on one GPU (the headline line is bench.py's):
 
   * EM step throughput of the 784-leaf model at the batch sizes the reference's experiments use
-    (100, 1 000, 7 500 = 60 000 / 8, 60 000);
+    (100, 1 000, 7 500 = 60 000 / 8, 60 000) and sizes in between, on float evidence and on one state
+    byte per leaf and observation;
   * inference-only throughput (enter_evidence + T iterations + log-likelihood, no E/M-step) on
     the 784-leaf model, the two docs networks and the loops network at 2^20 observations.
 
@@ -47,9 +48,14 @@ def median_time(fn, reps=5, warm=2):
     return statistics.median(times)
 
 
-def em_throughput(n, steps):
+def em_throughput(n, steps, states=False):
+    from bayesiannetwork_amd.inference_machines.evidence import HardEvidence
+
     network, ys = bench.build_model(ts, "c3a")
     batches = [bench.synthetic_evidence(ts, n, len(ys), 1 + b, device) for b in range(2)]
+    if states:  # the same evidence as one state byte per leaf and observation, resident on the device
+        batches = [HardEvidence(torch.stack([d.argmax(dim=1) for d in b.data]), [2] * len(ys), ts,
+                                on_value=1.0 - 1e-6, off_value=1e-6) for b in batches]
 
     def factory(net):
         return HipSpaInferenceMachine(SpaInferenceMachineSettings(ts, True), net, ys, n)
@@ -61,8 +67,8 @@ def em_throughput(n, steps):
         opt.optimize(bench._Batches([batches[i % 2] for i in range(steps)], n * steps))
 
     t = median_time(run)
-    return dict(workload="C3a EM step", batch=n, steps_per_repetition=steps, ms_per_step=t / steps * 1e3,
-                samples_per_s=n * steps / t)
+    return dict(workload="C3a EM step" + (" on resident state bytes" if states else ""), batch=n,
+                steps_per_repetition=steps, ms_per_step=t / steps * 1e3, samples_per_s=n * steps / t)
 
 
 def inference_throughput(label, network, observed, evidence, n, iterations=None, loops=False):
@@ -93,8 +99,11 @@ def resampled(fixture_name, n, seed=1, iterations=None, loops=False):
 
 def main():
     out = dict(device=torch.cuda.get_device_name(0), dtype="float32", results=[])
-    for n, steps in ((100, 200), (1000, 200), (7500, 100), (60000, 50)):
+    for n, steps in ((100, 200), (1000, 200), (2048, 200), (3072, 200), (4096, 100), (7500, 100), (16384, 50),
+                     (30000, 50), (60000, 50)):
         out["results"].append(em_throughput(n, steps))
+    for n, steps in ((4096, 100), (7500, 100), (16384, 50), (60000, 50)):
+        out["results"].append(em_throughput(n, steps, states=True))
     network, ys = bench.build_model(ts, "c3a")
     out["results"].append(inference_throughput("C3a 784-leaf", network, ys,
                                                bench.synthetic_evidence(ts, 60000, len(ys), 1, device), 60000))

@@ -24,8 +24,8 @@ rm -rf $OUT/stats
 #    counters, and the MFMA utilisation of the deep tree; each summary stamped with the commit and the
 #    kernels' signatures of this build
 cd $R
-for M in c3a c3b c5; do
-  if [ $M = c3a ]; then SUF=""; ARGS=""; else SUF="_$M"; ARGS="--model $M"; fi
+for M in c3a c3a_u8 c3b c5; do
+  if [ $M = c3a ]; then SUF=""; ARGS=""; elif [ $M = c3a_u8 ]; then SUF="_c3a_u8"; ARGS="--evidence resident-uint8"; else SUF="_$M"; ARGS="--model $M"; fi
   PMC_TAG=$SUF bash tools/pmc_traffic.sh $ARGS > $OUT/pmc_traffic$SUF.log 2>&1 || { echo "pmc traffic $M failed"; tail -5 $OUT/pmc_traffic$SUF.log; exit 1; }
   cp $R/gpurun_out/pmc_traffic$SUF.json $OUT/${TAG}_pmc_traffic$SUF.json
   PMC_TAG=$SUF bash tools/pmc_valu.sh $ARGS > $OUT/pmc_valu$SUF.log 2>&1 || { echo "pmc valu $M failed"; tail -5 $OUT/pmc_valu$SUF.log; exit 1; }
@@ -34,4 +34,9 @@ done
 bash tools/pmc_mfma.sh > $OUT/pmc_mfma.log 2>&1 || { echo "pmc mfma failed"; tail -5 $OUT/pmc_mfma.log; exit 1; }
 cp $R/gpurun_out/pmc_mfma.json $OUT/${TAG}_pmc_mfma_c5.json
 python3 tools/pmc_meta.py $OUT/${TAG}_bench_c3a_60k.json $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_valu.json $OUT/${TAG}_pmc_traffic_c3b.json $OUT/${TAG}_pmc_valu_c3b.json $OUT/${TAG}_pmc_traffic_c5.json $OUT/${TAG}_pmc_valu_c5.json $OUT/${TAG}_pmc_mfma_c5.json
+# (the same profile labels stand for other kernels on resident state bytes: stamped from that command's own line)
+python3 tools/pmc_meta.py $OUT/${TAG}_bench_c3a_60k_uint8.json $OUT/${TAG}_pmc_traffic_c3a_u8.json $OUT/${TAG}_pmc_valu_c3a_u8.json
+# 4. the EM step at other numbers of latent classes (cardinality packs) and the batch-size matrix
+timeout -k 10 500 python3 tools/latent_classes.py 5 8 10 11 12 13 16 20 24 32 > $OUT/${TAG}_latent_classes.json 2> $OUT/latent.err || { echo "latent classes failed"; tail -3 $OUT/latent.err; exit 1; }
+timeout -k 10 600 python3 tools/bench_matrix.py > $OUT/${TAG}_bench_matrix.json 2> $OUT/matrix.err || { echo "bench matrix failed"; tail -3 $OUT/matrix.err; exit 1; }
 ls -la $OUT
