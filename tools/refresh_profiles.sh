@@ -33,6 +33,8 @@ for M in c3a c3a_u8 c3b c5; do
 done
 bash tools/pmc_mfma.sh > $OUT/pmc_mfma.log 2>&1 || { echo "pmc mfma failed"; tail -5 $OUT/pmc_mfma.log; exit 1; }
 cp $R/gpurun_out/pmc_mfma.json $OUT/${TAG}_pmc_mfma_c5.json
+# (the passes' raw counter files are large: only the summaries are kept)
+rm -rf $R/gpurun_out/pmc $R/gpurun_out/pmc_* 2>/dev/null
 python3 tools/pmc_meta.py $OUT/${TAG}_bench_c3a_60k.json $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_valu.json $OUT/${TAG}_pmc_traffic_c3b.json $OUT/${TAG}_pmc_valu_c3b.json $OUT/${TAG}_pmc_traffic_c5.json $OUT/${TAG}_pmc_valu_c5.json $OUT/${TAG}_pmc_mfma_c5.json
 # (the same profile labels stand for other kernels on resident state bytes: stamped from that command's own line)
 python3 tools/pmc_meta.py $OUT/${TAG}_bench_c3a_60k_uint8.json $OUT/${TAG}_pmc_traffic_c3a_u8.json $OUT/${TAG}_pmc_valu_c3a_u8.json
