@@ -572,7 +572,9 @@ inline int prepare_fast(Plan& p) {
       FusedFamily& fam = st.fused[fi];
       if (fam.ll_part) continue;  // a two-parent group is visited from both its parents
       fam.ll_rows = fam.chunks;
-      fam.ll_rows_cap = std::max(fam.chunks, 32);
+      // rows for the reduce launch's own cut of the families: at small batches it wants many short chunks
+      // (about three resident waves per SIMD: 3 072 / tiles), each of which leaves one row
+      fam.ll_rows_cap = std::max(fam.chunks, (int32_t)std::min<int64_t>(128, std::max<int64_t>(32, 3072 / std::max<int64_t>(1, p.ntiles) + 1)));
       if (hipMalloc(reinterpret_cast<void**>(&fam.ll_part), (size_t)fam.ll_rows_cap * p.npad * sizeof(double)) != hipSuccess)
         return -2;
       p.device_bytes += (int64_t)((size_t)fam.ll_rows_cap * p.npad * sizeof(double));

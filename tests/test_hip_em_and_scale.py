@@ -722,6 +722,32 @@ def test_one_call_em_step_equals_the_separate_calls(name, hard, graphs):
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("classes", [10, 7])
 def test_one_launch_star_step_agrees_with_one_launch_per_pass(classes, dtype, n, hard):
+    _star_step_agreement(classes, dtype, n, hard)
+
+
+def test_streaming_one_launch_step_beyond_the_batch_sizes_it_is_used_for():
+    """The streaming one-launch step is used up to 3 072 observations because one launch per pass is
+    faster beyond; the kernel itself takes up to 256 slices of 128.  With the limit lifted
+    (BN_STREAM_MAX_SLICES, read once per process: hence a process of its own) it must still agree with
+    the launch-per-pass route at 4 096, 7 500 and 16 384 observations, on float evidence and on state
+    bytes."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, 'tests'); import test_hip_em_and_scale as t\n"
+            "for n in (4096, 7500, 16384):\n"
+            "    for hard in (False, True):\n"
+            "        t._star_step_agreement(10, 'float32', n, hard)\n"
+            "t._star_step_agreement(7, 'float64', 7500, False)\n"
+            "print('agreed')\n")
+    env = dict(os.environ, BN_STREAM_MAX_SLICES="256")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert done.returncode == 0 and "agreed" in done.stdout, done.stdout[-2000:] + done.stderr[-4000:]
+
+
+def _star_step_agreement(classes, dtype, n, hard):
     """The one-launch EM step of the 784-leaf model against the launch-per-pass route (itself checked
     against the oracle above): log-likelihoods and parameters after each of four steps, to
     rounding.  Up to 1 024 observations the kernel that keeps the evidence in registers, above that
