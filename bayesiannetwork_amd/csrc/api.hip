@@ -1037,9 +1037,11 @@ bool finish_shape_ok(bn_plan* plan) {
 
 // The tail of a whole step as one launch: what statistics_sums + m_step_rows do.  Returns 1 when the
 // plan's state does not allow it (the caller then takes those), BN_OK when launched.
+// accum_dev: where the count sums go (the plan's own buffer for a whole step); statistics_only: no M-step
 template <typename T>
 int launch_finish(bn_plan* plan, double learning_rate, double regularization, double ll_scale, double* ll_out_dev,
-                  void* new_cpts_dev, hipStream_t s, int32_t* ll_blocks) {
+                  void* new_cpts_dev, hipStream_t s, int32_t* ll_blocks, double* accum_dev = nullptr,
+                  bool statistics_only = false) {
   bn::Plan& p = plan->p;
   bn::FastState* fs = bn::fast_state(p);
   const auto& entry = *fs->fused.begin();
@@ -1079,7 +1081,8 @@ int launch_finish(bn_plan* plan, double learning_rate, double regularization, do
   a.forms = bn::form_sums_of(p, fam);
   a.cpts = static_cast<T*>(p.cpts);
   a.new_cpts = static_cast<T*>(new_cpts_dev);
-  a.accum = plan->accum_slot;
+  a.accum = accum_dev ? accum_dev : plan->accum_slot;
+  a.statistics_only = statistics_only ? 1 : 0;
   a.learning_rate = learning_rate;
   a.regularization = regularization;
   a.ll_scale = ll_scale;
@@ -2018,15 +2021,32 @@ int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const 
   plan->graphs_off = true;
   if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream)) return rc;
   int32_t ll_blocks = 0;
+  const double ll_scale = average ? 1.0 / (double)p.N : 1.0;
   t_discard_last_messages = true;
-  int rc = statistics_launches(p, num_iterations, 1, accum_dev, s, &ll_blocks);
+  int rc = BN_OK;
+  bool finished = false;
+  if (finish_shape_ok(plan)) {
+    // star plans: all the sums in one launch, as in bn_em_step (there with the M-step behind them)
+    rc = p.dtype == BN_F32 ? iterate_t<float>(p, num_iterations, 1, s) : iterate_t<double>(p, num_iterations, 1, s);
+    if (rc == BN_OK) {
+      const int done = p.dtype == BN_F32
+                           ? launch_finish<float>(plan, -1.0, 0.0, ll_scale, ll_out_dev, nullptr, s, &ll_blocks, accum_dev, true)
+                           : launch_finish<double>(plan, -1.0, 0.0, ll_scale, ll_out_dev, nullptr, s, &ll_blocks, accum_dev, true);
+      if (done < 0) rc = done;
+      finished = done == BN_OK;
+      if (rc == BN_OK && !finished) rc = statistics_sums(p, accum_dev, s, &ll_blocks);
+    }
+  } else {
+    rc = statistics_launches(p, num_iterations, 1, accum_dev, s, &ll_blocks);
+  }
   t_discard_last_messages = false;
   bn::set_ingest_next(p, false);
   bn::set_evidence_in_caller(p, false);
   bn::set_states_in_caller(p, false);
   if (rc != BN_OK) return rc;
+  if (finished) return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
   prof_begin("log_likelihood", (double)p.N * 8.0, s);
-  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, average ? 1.0 / (double)p.N : 1.0, ll_out_dev);
+  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, ll_scale, ll_out_dev);
   BN_LAUNCH_CHECK("sum_partials");
   prof_end(s);
   // nobody will query this batch's messages: the plan is as after bn_reset_messages

@@ -49,6 +49,9 @@ struct FinishArgs {
   double* ll_out;  // may be null: the caller sums ll_partial itself
   uint32_t* arrived;  // zero between launches
   FormSums forms;     // tab != nullptr: em_partial holds sums by evidence form (two-state leaves)
+  // 1: the statistics only (a rank's share of a sharded step: the sums go to accum and ll_out, the
+  // parameters are left alone)
+  int32_t statistics_only;
 };
 
 // one CPT row: target = counts / sum, regularised and blended as in m_step_rows (no fused multiply-add)
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
           for (int32_t j = 0; j < 4; ++j)
             if (j < a.S) a.accum[off + j] = counts[j];
         }
-        finish_row(a, off, a.S, counts);
+        if (!a.statistics_only) finish_row(a, off, a.S, counts);
       }
     } else {
       double counts[kFinishMaxStates];
@@ -137,7 +140,7 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
       if (lane == 0) {
         if (a.accum)
           for (int32_t j = 0; j < a.S; ++j) a.accum[off + j] = counts[j];
-        finish_row(a, off, a.S, counts);
+        if (!a.statistics_only) finish_row(a, off, a.S, counts);
       }
     }
     return;
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
     if (a.ll_out) a.ll_out[0] = red[0] * a.ll_scale;
     if (a.accum)
       for (int32_t j = 0; j < a.root_states; ++j) a.accum[a.root_cpt_off + j] = root_counts[j];
-    finish_row(a, a.root_cpt_off, a.root_states, root_counts);
+    if (!a.statistics_only) finish_row(a, a.root_cpt_off, a.root_states, root_counts);
   }
 }
 
