@@ -48,8 +48,11 @@ const CardinalityPack* cardinality_pack(int32_t d0) {
   if (d0 < 2 || d0 > 64) return nullptr;
   std::lock_guard<std::mutex> guard(lock);
   auto it = known.find(d0);
-  if (it == known.end()) it = known.emplace(d0, load_pack(d0)).first;
-  return it->second;
+  if (it != known.end()) return it->second;
+  // (a miss is not remembered: the pack may be built while the process runs; plans ask when they are compiled)
+  const CardinalityPack* pack = load_pack(d0);
+  if (pack) known.emplace(d0, pack);
+  return pack;
 }
 
 }  // namespace bn

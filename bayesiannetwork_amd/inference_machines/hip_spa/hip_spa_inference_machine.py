@@ -150,6 +150,29 @@ class _Topology:
 
 
 class HipSpaInferenceMachine(IInferenceMachine):
+    #: children from which on a node counts as a "wide parent" for the engine (csrc/plan.h: kWideFanIn)
+    _WIDE_FAN_IN = 24
+
+    def _serve_wide_cardinalities(self, topo) -> None:
+        """With ``BN_AUTO_PACKS=1`` in the environment, a many-children node whose number of states has
+        neither kernels in the library nor a cardinality pack gets its pack built before the plan is
+        compiled (``make pack``: a minute or two of hipcc, once per cardinality and installation);
+        without it such a node runs on the unfused kernels and a warning says what would help."""
+        import os
+        import warnings
+
+        for i, states in enumerate(topo.states):
+            children = topo.c_off[i + 1] - topo.c_off[i]
+            if children <= self._WIDE_FAN_IN or not 2 <= states <= 64 or self._lib.bn_cardinality_served(states):
+                continue
+            if os.environ.get("BN_AUTO_PACKS") == "1":
+                _native.build_cardinality_pack(states)
+            else:
+                warnings.warn(
+                    f"node {i} has {children} children and {states} states: no fused kernels for that many states "
+                    f"are installed, so it runs on the unfused ones (much slower).  `make pack D0={states}` "
+                    f"(or BN_AUTO_PACKS=1) builds them.", RuntimeWarning, stacklevel=3)
+
     def __init__(
         self,
         settings: SpaInferenceMachineSettings,
@@ -188,6 +211,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
             with torch.cuda.device(self._device):
                 _native.check(self._lib.bn_reset_messages(self._plan, self._stream()))
         else:
+            self._serve_wide_cardinalities(topo)
             handle = ctypes.c_void_p()
             with torch.cuda.device(self._device):
                 _native.check(
