@@ -1404,6 +1404,11 @@ int32_t bn_cardinality_served(int32_t states) {
   return bn::cardinality_pack(states) ? 2 : 0;
 }
 
+int32_t bn_two_parent_shape_served(int32_t d0, int32_t d1, int32_t s) {
+  if (bn::two_parent_shape(d0, d1, s)) return 1;
+  return bn::shape_pack(d0, d1, s) ? 2 : 0;
+}
+
 const char* bn_cardinality_pack_directory(void) { return bn::cardinality_pack_directory(); }
 
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {

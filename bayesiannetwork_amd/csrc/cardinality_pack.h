@@ -53,6 +53,16 @@ struct CardinalityPack {
 // BN_NO_PACKS is set).  Thread-safe; a pack stays loaded for the life of the process.
 const CardinalityPack* cardinality_pack(int32_t d0);
 
+// The same for the fused kernel of leaf families with two wide parents (leaf_family_p2, CPT shape
+// [D0][D1][S]): a fixed list of shapes is part of the library (BN_TWO_PARENT_SHAPES), any other is
+// pack2.hip compiled with -DBN_PACK2_D0= -DBN_PACK2_D1= -DBN_PACK2_S= into libbn_hip_p<D0>x<D1>x<S>.so
+// (make pack2 SHAPE=3x3x4).  mode: the kernel's MODE template argument, 0..8.
+struct ShapePack {
+  int32_t abi, d0, d1, s;
+  const void* (*leaf_family_p2)(int32_t dtype, int32_t mode);
+};
+const ShapePack* shape_pack(int32_t d0, int32_t d1, int32_t s);
+
 // where the library looks for packs (the directory it was loaded from); for messages and tools
 const char* cardinality_pack_directory();
 

@@ -333,7 +333,8 @@ inline int prepare_fast(Plan& p) {
     const FactorGroup& g = p.fgroups[fi];
     const int32_t num_parents = (int32_t)g.dims.size() - 1;
     if (num_parents == 2) {
-      if (!two_parent_shape(g.dims[0], g.dims[1], g.dims[2])) continue;  // the instantiated two-parent shapes
+      // the two-parent shapes with a fused kernel: in the library, or as a shape pack next to it
+      if (!two_parent_shape(g.dims[0], g.dims[1], g.dims[2]) && !shape_pack(g.dims[0], g.dims[1], g.dims[2])) continue;
     } else if (num_parents != 1 || !parent_dim(g.dims[0]) || !small_dim(g.dims[1])) {
       continue;
     }

@@ -128,6 +128,8 @@ inline LeafFamilyFn<T> leaf_family_p2_lookup(int32_t d0, int32_t d1, int32_t s) 
   if (d0 == A && d1 == B && s == C) return leaf_family_p2<T, A, B, C, kLeafVec, MODE>;
   BN_TWO_PARENT_SHAPES(X)
 #undef X
+  if (const ShapePack* pack = shape_pack(d0, d1, s))
+    return reinterpret_cast<LeafFamilyFn<T>>(const_cast<void*>(pack->leaf_family_p2(pack_dtype<T>(), MODE)));
   return nullptr;
 }
 

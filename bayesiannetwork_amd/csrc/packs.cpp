@@ -35,7 +35,36 @@ const CardinalityPack* load_pack(int32_t d0) {
   return pack;
 }
 
+const ShapePack* load_shape_pack(int32_t d0, int32_t d1, int32_t s) {
+  if (getenv("BN_NO_PACKS")) return nullptr;
+  const std::string path = library_directory() + "/libbn_hip_p" + std::to_string(d0) + "x" + std::to_string(d1) + "x" +
+                           std::to_string(s) + ".so";
+  void* handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!handle) return nullptr;
+  using Entry = const ShapePack* (*)();
+  Entry entry = reinterpret_cast<Entry>(dlsym(handle, "bn_shape_pack"));
+  const ShapePack* pack = entry ? entry() : nullptr;
+  if (!pack || pack->abi != kPackAbi || pack->d0 != d0 || pack->d1 != d1 || pack->s != s) {
+    dlclose(handle);
+    return nullptr;
+  }
+  return pack;
+}
+
 }  // namespace
+
+const ShapePack* shape_pack(int32_t d0, int32_t d1, int32_t s) {
+  static std::mutex lock;
+  static std::map<int64_t, const ShapePack*> known;
+  if (d0 < 2 || d1 < 2 || s < 2 || d0 > 64 || d1 > 64 || s > 64) return nullptr;
+  const int64_t key = ((int64_t)d0 << 32) | ((int64_t)d1 << 16) | s;
+  std::lock_guard<std::mutex> guard(lock);
+  auto it = known.find(key);
+  if (it != known.end()) return it->second;
+  const ShapePack* pack = load_shape_pack(d0, d1, s);  // (a miss is not remembered, as for cardinality packs)
+  if (pack) known.emplace(key, pack);
+  return pack;
+}
 
 const char* cardinality_pack_directory() {
   static const std::string dir = library_directory();

@@ -159,6 +159,12 @@ int32_t bn_star_barrier_verdict(uint32_t seen, uint32_t target);
  * every shape alike: spa_v3/factor_graph.py:339-395.)
  */
 int32_t bn_cardinality_served(int32_t states);
+/* The same question for the fused kernel of leaf families with two many-children parents (CPT shape
+ * [d0][d1][s]): ten shapes are part of the library, any other is a "shape pack",
+ * libbn_hip_p<d0>x<d1>x<s>.so (`make pack2 SHAPE=<d0>x<d1>x<s>`, ten seconds of hipcc; the Makefile's
+ * PACKS2 are built with the library).  1 = in the library, 2 = pack present (loaded by this call), 0 = neither:
+ * such families run on the unfused kernels. */
+int32_t bn_two_parent_shape_served(int32_t d0, int32_t d1, int32_t s);
 /* The directory the library looks for packs in (its own). */
 const char* bn_cardinality_pack_directory(void);
 

@@ -271,3 +271,14 @@ def test_cardinality_packs_are_found_next_to_the_library():
         assert table[1] == states  # {abi, d0, ...}
     for states in (1, 0, -3, 47, 65, 1000):
         assert lib.bn_cardinality_served(states) == 0
+    # shape packs (two-parent leaf families) export their own entry point and name their shape
+    shapes = sorted(glob.glob(os.path.join(directory, "libbn_hip_p*.so")))
+    assert len(shapes) >= 4
+    for path in shapes:
+        d0, d1, s = map(int, re.search(r"_p(\d+)x(\d+)x(\d+)\.so$", path).groups())
+        pack = ctypes.CDLL(path)
+        pack.bn_shape_pack.restype = ctypes.POINTER(ctypes.c_int32)
+        table = pack.bn_shape_pack()
+        assert (table[1], table[2], table[3]) == (d0, d1, s)
+        assert lib.bn_two_parent_shape_served(d0, d1, s) == 2
+    assert lib.bn_two_parent_shape_served(2, 2, 2) == 1 and lib.bn_two_parent_shape_served(7, 7, 7) == 0

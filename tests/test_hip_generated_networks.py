@@ -72,7 +72,9 @@ def _two_parent_loopy(gen):
     return spec, observed, 6, True
 
 
-TWO_PARENT_SHAPES = [(2, 2, 3), (2, 2, 4), (2, 3, 2), (3, 2, 2), (2, 3, 3), (3, 2, 3), (3, 3, 2), (3, 3, 3), (4, 4, 2)]
+# (the last four: shapes served by a shape pack, a shared object of its own per CPT shape)
+TWO_PARENT_SHAPES = [(2, 2, 3), (2, 2, 4), (2, 3, 2), (3, 2, 2), (2, 3, 3), (3, 2, 3), (3, 3, 2), (3, 3, 3), (4, 4, 2),
+                     (3, 3, 4), (2, 4, 2), (4, 2, 2), (2, 2, 5)]
 
 
 def _two_parent_shape(d0, d1, s):
