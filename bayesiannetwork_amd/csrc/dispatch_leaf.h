@@ -184,7 +184,7 @@ inline bool hard_family_fits(const Plan& p, const FactorGroup& g, const FusedFam
   if (!kernels.first || g.dims[1] != 2 || fam.src_stride == 0 || !fam.z_state) return false;
   if (hard_state_floats(K, g.dims[0]) > (size_t)K * (size_t)p.npad) return false;
   if (kernels.first_lds(fam.chunk_len) > kHardLdsMax) return false;
-  return kHardSBytes + kernels.rows_lds(hard_reduce_chunk_len(p, K, fam.ll_rows_cap)) <= kHardLdsMax;
+  return kernels.rows_lds(hard_reduce_chunk_len(p, K, fam.ll_rows_cap)) <= kHardLdsMax;
 }
 
 inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, const float* cpts, int32_t fresh,
@@ -236,7 +236,7 @@ inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     a.chunk_len = hard_reduce_chunk_len(p, a.K, fam.ll_rows_cap);
     a.chunks = (a.K + a.chunk_len - 1) / a.chunk_len;
     a.slots = (int32_t)(p.ntiles * 2);
-    lds_bytes = kHardSBytes + kernels.rows_lds(a.chunk_len);
+    lds_bytes = kernels.rows_lds(a.chunk_len);
   } else {
     return -1;
   }

@@ -497,20 +497,23 @@ __global__ void __launch_bounds__(256) hard_loop_light(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------
-// The sums over the wave's observations on the matrix cores: G[d][(family, form)] = sum_n P'[d][n] *
-// S[(family, form)][n] is a product of a 16 x 128 and a 128 x 16 matrix per eight families,
-// S[(k, y)][n] = scale of observation n for family k if the observation has form y, else 0.  P' sits
-// in registers in the operand layout for the whole chunk; the S rows go through LDS of the wave's
-// own (written per family as the scales come out, read back transposed every eight families), and
-// no sum crosses the lanes any other way.  Observations of the third form (rare) are added with
-// atomics to sums of their own (hard_third_sums), already weighted for forms 0 and 1.
+// The count sums on the matrix cores.  The leaves' messages to the parent are the q of the step
+// from the second iteration on, so the parent's scaled products of two iterations differ by a
+// factor per observation only, and a family's joint posterior of an observation n of form y is
+//   cpt[d][j] * ev(y)[j] / q[y][d] * b[d][n],   b[.][n] = P'[.][n] / sum_d P'[d][n]
+// with the parent's posterior b the same for all families.  The sums by form are therefore
+//   G[d][(family, form)] = sum_n b[d][n] * S[(family, form)][n],   S = 1 where n has that form, else 0,
+// a product of a 16 x 128 and a 128 x 16 matrix per eight families and wave: b sits in registers in
+// the operand layout for the whole chunk, and S comes straight from the state bytes (a lane reads
+// the 32 bytes of its column and quarter of the wave's observations).  Observations of the third
+// form (rare) are added with atomics to sums of their own (hard_third_sums), already weighted for
+// forms 0 and 1.  What is left per family and observation is the leaf's normaliser of this
+// iteration for the log-likelihood, formed again from the previous P' as hard_loop_light forms it.
 //
 // a.chunks / a.chunk_len: the launch's own cut of the families (it writes no partial products, so it
 // need not follow the parent's chunks); a.slots: per-wave sum slots per entry (ntiles * 2).
 // em_partial[k][d * 2 + y][slot]: the wave's share of G[y][d] (see hard_count).
-constexpr int32_t kHardGroup = 8;       // families per matrix product
-constexpr int32_t kHardSRow = 128 + 4;  // floats per S row in LDS (padded: the transposed reads spread over the banks)
-constexpr size_t kHardSBytes = (size_t)kWavesPerBlock * 2 * kHardGroup * kHardSRow * sizeof(float);
+constexpr int32_t kHardGroup = 8;  // families per matrix product
 
 // [K][2][D0] sums of the third-form observations, behind the records
 template <int D0>
@@ -518,12 +521,18 @@ __device__ __forceinline__ float* hard_third_sums(const float* tab, int32_t K) {
   return const_cast<float*>(tab) + hard_table_floats(K, D0);
 }
 
-// one observation of the third form: P'[d] * scale, weighted for forms 0 and 1, onto the family's sums
+// one observation of the third form: b[d], weighted for forms 0 and 1, onto the family's sums
 template <int D0>
-__device__ __attribute__((noinline)) void hard_third_add(const float* tab, const double* scaled, int64_t npad, int32_t K,
-                                                         int32_t k, int64_t obs, float scale) {
+__device__ __forceinline__ void hard_third_add(const float* tab, const double* scaled, int64_t npad, int32_t K, int32_t k,
+                                               int64_t obs) {
   const float* rec = tab + (size_t)k * (kHardRows * D0);
   float* third = hard_third_sums<D0>(tab, K) + (size_t)k * (2 * D0);
+  // (rare: compact loops, so that the callers stay small and hold nothing for this in registers)
+  float sum = 0.f;
+#pragma unroll 1
+  for (int32_t d = 0; d < D0; ++d) sum += (float)scaled[(int64_t)d * npad + obs];
+  const float scale = fast_rcp(sum);
+#pragma unroll 1
   for (int32_t d = 0; d < D0; ++d) {
     const float x = (float)scaled[(int64_t)d * npad + obs] * scale;
     atomicAdd(third + d, x * rec[kHardThird * D0 + d]);
@@ -531,134 +540,206 @@ __device__ __attribute__((noinline)) void hard_third_add(const float* tab, const
   }
 }
 
+// the state bytes [n0, n0 + 32) of one leaf's row (any alignment; n0 and N are even).  WHOLE: they all lie
+// before the row's end; otherwise bytes past the end read as state 0 (pairs of bytes from addresses
+// that always exist, all in flight together: a wave of the last tile must not take longer than the others)
+template <bool WHOLE>
+__device__ __forceinline__ void hard_states32(const uint8_t* row, int64_t n0, int64_t N, uint32_t* out) {
+  if constexpr (WHOLE) {
+    uint4 lo, hi;
+    __builtin_memcpy(&lo, row + n0, 16);
+    __builtin_memcpy(&hi, row + n0 + 16, 16);
+    out[0] = lo.x, out[1] = lo.y, out[2] = lo.z, out[3] = lo.w;
+    out[4] = hi.x, out[5] = hi.y, out[6] = hi.z, out[7] = hi.w;
+  } else {
+    uint16_t two[16];
+#pragma unroll
+    for (int32_t x = 0; x < 16; ++x) {
+      const int64_t n = n0 + 2 * x;
+      __builtin_memcpy(&two[x], row + (n + 2 <= N ? n : 0), 2);
+    }
+#pragma unroll
+    for (int32_t x = 0; x < 8; ++x) {
+      const int64_t n = n0 + 4 * x;
+      const uint32_t lo = n + 2 <= N ? two[2 * x] : 0u, hi = n + 4 <= N ? two[2 * x + 1] : 0u;
+      out[x] = lo | (hi << 16);
+    }
+  }
+}
+
+// x + the same value of the lanes 8, 4, 2 and 1 further on in the row of 16: every lane ends with the row's sum
+__device__ __forceinline__ float hard_row_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int32_t, x), 0x128, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int32_t, x), 0x124, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int32_t, x), 0x122, 0xf, 0xf, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int32_t, x), 0x121, 0xf, 0xf, false));
+  return x;
+}
+
 template <int D0>
 __global__ void __launch_bounds__(256) hard_reduce_mfma(const float* __restrict__ cpts, LeafFamilyArgs<float> a) {
   static_assert(D0 <= 16, "one 16-row operand holds the parent's states");
+  static_assert(kHardRing == kHardGroup, "one ring of state bytes per matrix product");
   constexpr int32_t V = 2, E = D0 * 2;
   using Stage = HardStage<D0, false>;
   typedef float float4v __attribute__((ext_vector_type(4)));
-  extern __shared__ __align__(16) float hard_staged[];  // the S rows of the four waves, then the chunk's rows
+  extern __shared__ __align__(16) float hard_staged[];  // the chunk's rows
   HardWave<D0> w;
   w.place(a, a.chunk_len);
   const float* tab = a.hard_tab;
-  float* rows_staged = hard_staged + kHardSBytes / sizeof(float);
-  Stage::fill(tab, w.first, w.last, kHardRq, rows_staged);
+  Stage::fill(tab, w.first, w.last, kHardRq, hard_staged);
   if (!w.active) return;
-  float* s_rows = hard_staged + (size_t)w.wave * (2 * kHardGroup * kHardSRow);
 
-  fv<float, V> pf[D0], prev[D0];
-  hard_load_scaled<D0>(a.scaled, a.npad, w.obs0, pf);
-  hard_load_scaled<D0>(a.scaled_prev, a.npad, w.obs0, prev);
-  fv<float, V> prev_sum = prev[0];
+  // ---- the leaves' normalisers of this iteration, two families per turn: z = sum(P') / sum(P' / q) of
+  // the previous P' (the operations of the loop launch that was left out)
+  bool saw_third = false;  // any observation of the third form among the wave's (the same in all lanes)
+  {
+    fv<float, V> prev[D0];
+    hard_load_scaled<D0>(a.scaled_prev, a.npad, w.obs0, prev);
+    fv<float, V> prev_sum = prev[0];
 #pragma unroll
-  for (int32_t i = 1; i < D0; ++i) prev_sum += prev[i];
-  // P' as the 16 x 4 operand of each of the 32 steps: lane (i = lane % 16, kk = lane / 16) holds state i of
-  // observations 32 kk .. 32 kk + 31 of the wave's 128
+    for (int32_t i = 1; i < D0; ++i) prev_sum += prev[i];
+    double pz[V] = {1.0, 1.0};
+    int32_t pze[V] = {0, 0};
+    int32_t until_renorm = 6;  // six float factors cannot leave the double range
+    uint32_t ring[kHardRing], behind[kHardRing];
+#pragma unroll
+    for (int32_t u = 0; u < kHardRing; ++u) {
+      ring[u] = w.pair(w.first + u < w.last ? w.first + u : w.last - 1);
+      behind[u] = w.pair(w.first + kHardRing + u < w.last ? w.first + kHardRing + u : w.last - 1);
+    }
+    for (int32_t k0 = w.first; k0 < w.last; k0 += kHardRing) {
+#pragma unroll
+      for (int32_t u = 0; u < kHardRing; u += 2) {
+        const int32_t k = k0 + u;
+        if (k >= w.last) break;
+        const bool both = k + 1 < w.last;
+        const uint32_t pair_a = ring[u], pair_b = ring[u + 1];
+        ring[u] = behind[u];
+        ring[u + 1] = behind[u + 1];
+        behind[u] = w.pair(k + 2 * kHardRing < w.last ? k + 2 * kHardRing : w.last - 1);
+        behind[u + 1] = w.pair(k + 1 + 2 * kHardRing < w.last ? k + 1 + 2 * kHardRing : w.last - 1);
+        HardRows<D0> rq_a, rq_b;
+        rq_a.load(hard_staged + (size_t)(k - w.first) * Stage::kStride);
+        rq_b.load(hard_staged + (size_t)(both ? k + 1 - w.first : k - w.first) * Stage::kStride);
+        const HardForms fa(pair_a), fb(pair_b);
+        fv<float, V> sum_a, sum_b;
+        const bool any_third = fa.any_third() || fb.any_third();
+        saw_third |= any_third;
+        hard_dot_own2<D0>(prev, tab, k, both ? k + 1 : k, kHardRq + 2, rq_a, rq_b, fa, fb, any_third, &sum_a, &sum_b);
+        const fv<float, V> z_a = prev_sum * rcpv<float, V>(sum_a);
+        fv<float, V> z_b = prev_sum * rcpv<float, V>(sum_b);
+        if (!both) z_b = splat<float, V>(1.0f);
+#pragma unroll
+        for (int32_t v = 0; v < V; ++v) pz[v] *= (double)z_a[v] * (double)z_b[v];
+        until_renorm -= 2;
+        if (until_renorm <= 0) {
+          until_renorm = 6;
+#pragma unroll
+          for (int32_t v = 0; v < V; ++v) pze[v] += frexp_in_place(pz[v]);
+        }
+      }
+    }
+    double* dst = a.ll_part + (int64_t)w.chunk * a.npad + w.obs0;
+#pragma unroll
+    for (int32_t v = 0; v < V; ++v) {
+      int de = 0;
+      const double m = frexp(pz[v], &de);
+      dst[v] = (double)(pze[v] + de) * 0.6931471805599453 + log(m);
+    }
+  }
+  if (!a.em_partial) return;
+  if (saw_third) {
+    // (rare) every lane looks at its own two observations of every family once more
+#pragma unroll 1
+    for (int32_t k = w.first; k < w.last; ++k) {
+      const HardForms f(w.pair(k));
+#pragma unroll
+      for (int32_t v = 0; v < V; ++v)
+        if (f.third[v] && w.obs0 + v < a.N) hard_third_add<D0>(tab, a.scaled, a.npad, a.K, k, w.obs0 + v);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // nothing of the second pass is started (and held in registers) during the first
+
+  // ---- the sums by form.  b as the 16 x 4 operand of each of the 32 steps: lane (i = lane % 16, kk = lane / 16)
+  // holds state i of observations 32 kk .. 32 kk + 31 of the wave's 128 (zero for the states and
+  // observations there are not)
   const int32_t op_i = w.lane & 15, op_kk = w.lane >> 4;
+  const int64_t op_n0 = w.t * 256 + w.part * 128 + op_kk * 32;
   float p_op[32];
   {
-    const int64_t n0 = w.t * 256 + w.part * 128 + op_kk * 32;
-    const double* src = a.scaled + (int64_t)(op_i < D0 ? op_i : 0) * a.npad + n0;
+    const double* src = a.scaled + (int64_t)(op_i < D0 ? op_i : 0) * a.npad + op_n0;
+    double2 raw[16];  // all in flight together
+#pragma unroll
+    for (int32_t t = 0; t < 16; ++t) raw[t] = *reinterpret_cast<const double2*>(src + 2 * t);
 #pragma unroll
     for (int32_t t = 0; t < 32; t += 2) {
-      const double2 two = *reinterpret_cast<const double2*>(src + t);
-      p_op[t] = (op_i < D0 && n0 + t < a.N) ? (float)two.x : 0.f;
-      p_op[t + 1] = (op_i < D0 && n0 + t + 1 < a.N) ? (float)two.y : 0.f;
-      // converted here and now (left alone the conversions sink into the loop, and the doubles stay live)
-      asm volatile("" : "+v"(p_op[t]), "+v"(p_op[t + 1]));
+      p_op[t] = (op_i < D0 && op_n0 + t < a.N) ? (float)raw[t >> 1].x : 0.f;
+      p_op[t + 1] = (op_i < D0 && op_n0 + t + 1 < a.N) ? (float)raw[t >> 1].y : 0.f;
+    }
+    // converted here and now (left alone the conversions sink into the loop, and the doubles stay live)
+#pragma unroll
+    for (int32_t t = 0; t < 32; ++t) asm volatile("" : "+v"(p_op[t]));
+#pragma unroll
+    for (int32_t t = 0; t < 32; ++t) {
+      const float sum = hard_row_sum(p_op[t]);
+      p_op[t] *= op_n0 + t < a.N ? fast_rcp(sum) : 0.f;
     }
   }
-  double pz[V] = {1.0, 1.0};
-  int32_t pze[V] = {0, 0};
-  const bool live[V] = {w.obs0 < a.N, w.obs0 + 1 < a.N};
   const int32_t slot = (int32_t)(w.t * 2 + w.part);
-
-  uint32_t ring[kHardRing], behind[kHardRing];
-#pragma unroll
-  for (int32_t u = 0; u < kHardRing; ++u) {
-    ring[u] = w.pair(w.first + u < w.last ? w.first + u : w.last - 1);
-    behind[u] = w.pair(w.first + kHardRing + u < w.last ? w.first + kHardRing + u : w.last - 1);
-  }
+  // the state bytes of column j = (family k0 + j / 2, form j % 2) in the operand layout, one group ahead
+  const int32_t op_k = op_i >> 1;
+  const uint32_t op_y = (uint32_t)(op_i & 1) * 0x01010101u;
+  auto sums = [&](auto whole) {
+  constexpr bool kWhole = decltype(whole)::value;
+  uint32_t sb[8];
+  hard_states32<kWhole>(w.states + (int64_t)(w.first + op_k < w.last ? w.first + op_k : w.last - 1) * w.stride, op_n0, a.N, sb);
   for (int32_t k0 = w.first; k0 < w.last; k0 += kHardGroup) {
-#pragma unroll 1
-    for (int32_t u0 = 0; u0 < kHardGroup; u0 += kHardRing) {
+    uint32_t sb_next[8];
+    {
+      const int32_t kn = k0 + kHardGroup + op_k;
+      hard_states32<kWhole>(w.states + (int64_t)(kn < w.last ? kn : w.last - 1) * w.stride, op_n0, a.N, sb_next);
+    }
+    const int32_t k = k0 + op_k;
+    // one byte per observation: 1 where it has this column's form
+    uint32_t is[8], beyond = 0;
 #pragma unroll
-      for (int32_t ur = 0; ur < kHardRing; ++ur) {
-        const int32_t u = u0 + ur, k = k0 + u;
-        if (k >= w.last) break;
-        const uint32_t pair = ring[ur];
-        ring[ur] = behind[ur];
-        behind[ur] = w.pair(k + 2 * kHardRing < w.last ? k + 2 * kHardRing : w.last - 1);
-        HardRows<D0> rq;
-        rq.load(rows_staged + (size_t)(k - w.first) * Stage::kStride);
-        const HardForms f(pair);
-        const bool any_third = f.any_third();
-        // the leaf's normaliser of this iteration, formed again from the previous P' (the operations of
-        // the loop launch that was left out), and the sum of the parent's message from the current one
-        const fv<float, V> sum_r = hard_dot_own<D0>(prev, tab, k, kHardRq + 2, rq, f, any_third);
-        const fv<float, V> z = prev_sum * rcpv<float, V>(sum_r);
-        const fv<float, V> inv_sum = rcpv<float, V>(hard_dot_own<D0>(pf, tab, k, kHardRq + 2, rq, f, any_third));
+    for (int32_t x = 0; x < 8; ++x) {
+      beyond |= sb[x] & 0xfefefefeu;
+      is[x] = (sb[x] ^ op_y ^ 0x01010101u) & 0x01010101u;
+    }
+    if (beyond) {
+      // third-form observations belong to neither column (their share goes to sums of their own, below)
 #pragma unroll
-        for (int32_t v = 0; v < V; ++v) pz[v] *= (double)z[v];
-        if (renorm_due<float>(k - w.first + 1)) {
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v) {
-            int de = 0;
-            pz[v] = frexp(pz[v], &de);
-            pze[v] += de;
-          }
-        }
-        if (a.em_partial) {
-          const fv<float, V> scale = recipv<float, V>(z) * inv_sum;
-          fv<float, V> row0, row1;  // this lane's two entries of S[(k, 0)] and S[(k, 1)]
-#pragma unroll
-          for (int32_t v = 0; v < V; ++v) {
-            const float s = (live[v] && !f.third[v]) ? scale[v] : 0.f;
-            row0[v] = f.one[v] ? 0.f : s;
-            row1[v] = f.one[v] ? s : 0.f;
-          }
-          *reinterpret_cast<fv<float, V>*>(s_rows + (size_t)(u * 2) * kHardSRow + w.lane * V) = row0;
-          *reinterpret_cast<fv<float, V>*>(s_rows + (size_t)(u * 2 + 1) * kHardSRow + w.lane * V) = row1;
-          if (any_third) {
-#pragma unroll
-            for (int32_t v = 0; v < V; ++v)
-              if (f.third[v] && live[v]) hard_third_add<D0>(tab, a.scaled, a.npad, a.K, k, w.obs0 + v, scale[v]);
-          }
-        }
+      for (int32_t x = 0; x < 8; ++x) {
+        const uint32_t t = sb[x] & 0xfefefefeu;
+        is[x] &= ~(((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u) >> 7);
       }
     }
-    if (a.em_partial) {
-      // the group's 16 S rows against P': lane (j = lane % 16, kk) supplies row j's entries 32 kk ..
-      const float* mine = s_rows + (size_t)op_i * kHardSRow + op_kk * 32;
-      float4v sum = {0.f, 0.f, 0.f, 0.f};
+    float4v sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int32_t t = 0; t < 32; t += 8) {
-        // two reads at a time (the scheduler would otherwise hold all 32 values at once)
-        const float4v b0 = *reinterpret_cast<const float4v*>(mine + t), b1 = *reinterpret_cast<const float4v*>(mine + t + 4);
+    for (int32_t t = 0; t < 32; ++t) {
+      const float s = (float)((is[t >> 2] >> (8 * (t & 3))) & 0xffu);
+      sum = __builtin_amdgcn_mfma_f32_16x16x4f32(p_op[t], s, sum, 0, 0, 0);
+    }
+    // lane (j, kk) holds states 4 kk .. 4 kk + 3 of column j
+    if (k < w.last) {
+      const int32_t y = op_i & 1;
 #pragma unroll
-        for (int32_t x = 0; x < 4; ++x) sum = __builtin_amdgcn_mfma_f32_16x16x4f32(p_op[t + x], b0[x], sum, 0, 0, 0);
-#pragma unroll
-        for (int32_t x = 0; x < 4; ++x) sum = __builtin_amdgcn_mfma_f32_16x16x4f32(p_op[t + 4 + x], b1[x], sum, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // lane (j, kk) holds states 4 kk .. 4 kk + 3 of column j = (family k0 + j / 2, form j % 2)
-      const int32_t k = k0 + (op_i >> 1), y = op_i & 1;
-      if (k < w.last) {
-#pragma unroll
-        for (int32_t x = 0; x < 4; ++x) {
-          const int32_t d = op_kk * 4 + x;
-          if (d < D0) a.em_partial[((int64_t)k * E + d * 2 + y) * a.slots + slot] = sum[x];
-        }
+      for (int32_t x = 0; x < 4; ++x) {
+        const int32_t d = op_kk * 4 + x;
+        if (d < D0) a.em_partial[((int64_t)k * E + d * 2 + y) * a.slots + slot] = sum[x];
       }
     }
-  }
-  double* dst = a.ll_part + (int64_t)w.chunk * a.npad + w.obs0;
 #pragma unroll
-  for (int32_t v = 0; v < V; ++v) {
-    int de = 0;
-    const double m = frexp(pz[v], &de);
-    dst[v] = (double)(pze[v] + de) * 0.6931471805599453 + log(m);
+    for (int32_t x = 0; x < 8; ++x) sb[x] = sb_next[x];
   }
+  };
+  // (a wave whose observations all exist - all but the last tile's - reads its state bytes without looking)
+  if (w.t * 256 + w.part * 128 + 128 <= a.N)
+    sums(std::true_type{});
+  else
+    sums(std::false_type{});
 }
 
 }  // namespace bn
