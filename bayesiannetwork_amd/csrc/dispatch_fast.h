@@ -115,6 +115,9 @@ inline void invalidate_fast(Plan& p) {
       kv.second.pending = false;
       kv.second.em_ready = false;
       kv.second.z_form = kZNone;
+      kv.second.hard_z_mant = nullptr;
+      kv.second.hard_z_exp = nullptr;
+      kv.second.hard_wants_light = false;
     }
     std::fill(st->root_written.begin(), st->root_written.end(), 0);
   }
@@ -1056,6 +1059,8 @@ inline void append_state_signature(const Plan& p, std::string& key) {
     put(fam.ll_rows);
     put(fam.slots_used);
     put(fam.em_by_form);
+    put(fam.hard_z_mant);
+    put(fam.hard_wants_light);
   }
 }
 

@@ -168,11 +168,11 @@ inline HardKernels hard_kernels(int32_t d0) {
 
 constexpr size_t kHardLdsMax = 64 * 1024;  // per block, so that at least two blocks share a CU
 
-// the reduce launch's own cut of a group's K families: chunk length (whole groups of eight)
-inline int32_t hard_reduce_chunk_len(const Plan& p, int32_t K, int32_t rows_cap) {
-  int64_t want = std::max<int64_t>(1, 4096 / (p.ntiles * 2));  // about four resident waves per SIMD
-  if (env_reduce_chunks() > 0) want = env_reduce_chunks();
-  const int32_t chunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, rows_cap), K));
+// the reduce launch's own cut of a group's K families: chunk length (whole groups of sixteen, as many as a wave
+// keeps sums for)
+inline int32_t hard_reduce_chunk_len(int32_t K) {
+  const int32_t most = kHardSumGroups * kHardGroup;
+  const int32_t chunks = (K + most - 1) / most;
   const int32_t len = (K + chunks - 1) / chunks;
   return (len + kHardGroup - 1) / kHardGroup * kHardGroup;
 }
@@ -183,8 +183,8 @@ inline bool hard_family_fits(const Plan& p, const FactorGroup& g, const FusedFam
   const int32_t K = (int32_t)g.nodes.size();
   if (!kernels.first || g.dims[1] != 2 || fam.src_stride == 0 || !fam.z_state) return false;
   if (hard_state_floats(K, g.dims[0]) > (size_t)K * (size_t)p.npad) return false;
-  if (kernels.first_lds(fam.chunk_len) > kHardLdsMax) return false;
-  return kernels.rows_lds(hard_reduce_chunk_len(p, K, fam.ll_rows_cap)) <= kHardLdsMax;
+  if (!hard_states_addressable(K, fam.src_stride, p.N)) return false;
+  return kernels.first_lds(fam.chunk_len) <= kHardLdsMax;
 }
 
 inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, const float* cpts, int32_t fresh,
@@ -221,22 +221,25 @@ inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   HardFn fn = nullptr;
   size_t lds_bytes = 0;
   if (mode == kLeafLoop) {
-    if (next_is_last) return -1;  // (the launch before the reduce launch is left out: leaf_launch_folds)
     if (fresh) {
+      if (next_is_last) return -1;  // (a reduce launch needs the normalisers of a light launch)
       fn = kernels.first;
       lds_bytes = kernels.first_lds(a.chunk_len);
     } else {
+      // (the launch before the reduce launch is left out when a light launch has run: leaf_launch_folds)
       if (first_iteration || fam.z_form != kZPerChunk) return -1;
       fn = kernels.light;
-      lds_bytes = kernels.rows_lds(a.chunk_len);
+      lds_bytes = kHardLogBytes;
     }
   } else if (mode == kLeafReduce) {
-    if (fresh || first_iteration || fam.z_form != kZRecompute) return -1;
+    if (fresh || first_iteration || !fam.hard_z_mant || fam.chunks > fam.ll_rows_cap) return -1;
     fn = kernels.reduce;
-    a.chunk_len = hard_reduce_chunk_len(p, a.K, fam.ll_rows_cap);
+    a.zdiv_next_mant = fam.hard_z_mant;
+    a.zdiv_next_exp = fam.hard_z_exp;
+    a.z_rows = fam.chunks;
+    a.chunk_len = hard_reduce_chunk_len(a.K);
     a.chunks = (a.K + a.chunk_len - 1) / a.chunk_len;
-    a.slots = (int32_t)(p.ntiles * 2);
-    lds_bytes = kernels.rows_lds(a.chunk_len);
+    a.slots = hard_sum_slots(p.ntiles);
   } else {
     return -1;
   }
@@ -248,7 +251,7 @@ inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     launch(kernels.tables, dim3((uint32_t)(((size_t)a.K * g.dims[0] + 255) / 256)), dim3(256), 0, s, cpts, a, static_cast<float*>(fam.z_state));
     if (!launch_ok()) return -1;
   }
-  launch(fn, dim3(hard_blocks(a.chunks, p.ntiles)), dim3(256), lds_bytes, s, cpts, a);
+  launch(fn, dim3(mode == kLeafReduce ? hard_sum_blocks(a.chunks, p.ntiles) : hard_blocks(a.chunks, p.ntiles)), dim3(256), lds_bytes, s, cpts, a);
   if (!launch_ok()) return -1;
   if (mode == kLeafLoop) {
     fam.z_form = kZPerChunk;
@@ -256,8 +259,11 @@ inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
     fam.em_ready = false;
     w.partials_valid = true;
     if (fresh) w.products_cached = false;  // the first launch rewrote the chunks' partial products
+    fam.hard_wants_light = fresh != 0;
+    fam.hard_z_mant = fresh ? nullptr : a.zdiv_next_mant;
+    fam.hard_z_exp = fresh ? nullptr : a.zdiv_next_exp;
   } else {
-    fam.ll_rows = a.chunks;
+    fam.ll_rows = a.z_rows;
     fam.slots_used = a.slots;
     fam.em_by_form = true;
     fam.pending = true;
@@ -286,6 +292,9 @@ int launch_leaf_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNode& w, W
     if (fast_state(p)->states_in_caller && !w2 && g.dims[1] == 2)
       return launch_hard_family(p, g, fam, w, cpts, fresh, first_iteration, mode, s, with_counts, next_is_last);
   }
+  fam.hard_wants_light = false;  // (launches of the other kind leave nothing for a reduce launch on state bytes)
+  fam.hard_z_mant = nullptr;
+  fam.hard_z_exp = nullptr;
   const int32_t state = fresh ? kLeafFresh
                               : (first_iteration ? kLeafFromArrays : (fam.z_form == kZRecompute ? kLeafRecompute : kLeafSteady));
   const bool ingest_wanted = fresh && !w2 && g.dims[1] == 2 && fast_state(p)->ingest_next;

@@ -84,6 +84,13 @@ struct FusedFamily {
   int32_t ll_rows_cap = 0;      // rows allocated
   int32_t slots_used = 0;       // per-wave sum slots the last reduce-mode launch wrote
   bool em_by_form = false;      // ... as sums by evidence form (kernels_hard.h), not by CPT entry
+  // State bytes read in place (kernels_hard.h): the products of the leaves' normalisers the last
+  // hard_loop_light launch left, per chunk of the parent - the reduce launch turns them into its rows of
+  // normalisers (null: no such launch since the messages were fresh) - and whether the call's first launch
+  // has run without one yet (then the loop launch before the reduce launch is not left out)
+  double* hard_z_mant = nullptr;
+  int32_t* hard_z_exp = nullptr;
+  bool hard_wants_light = false;
   // the last iteration ran in reduce mode: stored messages are one iteration behind until
   // complete_pending_fast re-runs it in full mode with these flags
   bool pending = false;
@@ -207,7 +214,7 @@ inline bool env_reduce_v2() {
 inline bool leaf_launch_folds(const FusedFamily& fam, bool loop_mode, int32_t next_is_last, int32_t fresh,
                               int32_t first_iteration) {
   return loop_mode && fam.wide_index2 < 0 && next_is_last == 2 && !fresh && !first_iteration &&
-         fam.z_form == kZPerChunk && !env_no_recompute();
+         fam.z_form == kZPerChunk && !fam.hard_wants_light && !env_no_recompute();
 }
 
 }  // namespace bn

@@ -58,6 +58,8 @@ struct LeafFamilyArgs {
   // work item, each taking a quarter of the chunk's families (small batches: as many waves as
   // before, a quarter of the chunk partials for the parent's combine to read)
   int32_t split;
+  // hard_reduce_mfma only: the rows of normalisers' products the last hard_loop_light launch left (in zdiv_next_*)
+  int32_t z_rows;
 };
 // Template parameter MODE
 //   kLeafLoop    inside a bn_iterate call: only the loop state is written (one-parent families run
