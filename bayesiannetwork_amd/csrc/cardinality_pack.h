@@ -16,7 +16,7 @@
 
 namespace bn {
 
-constexpr int32_t kPackAbi = 1;  // bumped whenever a kernel's arguments or this table change
+constexpr int32_t kPackAbi = 2;  // bumped whenever a kernel's arguments or this table change
 
 struct LeafLoopRef {
   const void* fn;
@@ -35,7 +35,6 @@ struct WideKernelRefs {
 struct HardKernelRefs {
   const void *first, *light, *reduce, *tables;
   size_t (*first_lds)(int32_t chunk_len);
-  size_t (*rows_lds)(int32_t chunk_len);
 };
 
 // dtype: 0 float, 1 double (bn_dtype).  mode / out / from: the kernels' template arguments

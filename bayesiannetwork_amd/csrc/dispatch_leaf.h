@@ -140,13 +140,13 @@ using HardTablesFn = void (*)(const float*, LeafFamilyArgs<float>, float*);
 struct HardKernels {
   HardFn first = nullptr, light = nullptr, reduce = nullptr;
   HardTablesFn tables = nullptr;
-  size_t (*first_lds)(int32_t) = nullptr, (*rows_lds)(int32_t) = nullptr;  // staged rows of a chunk of that many families
+  size_t (*first_lds)(int32_t) = nullptr;  // LDS of the first launch: the staged rows of a chunk of that many families
 };
 template <int D0>
 inline HardKernels hard_kernels_for() {
   if constexpr (D0 <= 16)
     return {hard_loop_first<D0>, hard_loop_light<D0>, hard_reduce_mfma<D0>, hard_tables_build<D0>,
-            HardStage<D0, true>::bytes, HardStage<D0, false>::bytes};
+            HardStage<D0, true>::bytes};
   return {};
 }
 inline HardKernels hard_kernels(int32_t d0) {
@@ -161,7 +161,7 @@ inline HardKernels hard_kernels(int32_t d0) {
     const HardKernelRefs r = pack->hard();
     return {reinterpret_cast<HardFn>(const_cast<void*>(r.first)), reinterpret_cast<HardFn>(const_cast<void*>(r.light)),
             reinterpret_cast<HardFn>(const_cast<void*>(r.reduce)), reinterpret_cast<HardTablesFn>(const_cast<void*>(r.tables)),
-            r.first_lds, r.rows_lds};
+            r.first_lds};
   }
   return {};
 }

@@ -7,25 +7,24 @@
 // versions per family: q[y][d] = cpt[d] . ev(y), 1 / q[y][d] and log2 q[y][d].  hard_tables_build
 // writes these once per step (the parameters do not change inside one), q and 1 / q with the very
 // operations the float kernels apply to the expanded evidence.  No product with the evidence and
-// no reciprocal per state is left in the family loops, and a family's evidence is 2 bytes per lane
-// instead of 16:
-//   * a dot product with a family's row is computed for both common forms at once (the rows are the
-//     same for all lanes: two fused multiply-adds per state serve a lane's two observations) and
-//     every observation keeps the result of its own form;
+// no reciprocal per state is left in the family loops:
 //   * the per-state product of the q over a chunk's families is carried as a sum of logarithms in
-//     double, one fused multiply-add per family and state (hard_loop_first);
-//   * the count sums factor into sums by evidence form, which are matrix products over the
-//     observations and run on the matrix cores (hard_reduce_mfma).
-// A block's four waves work on the same chunk of families (each on its own 128 observations) and
-// stage the chunk's rows in LDS once; every wave then reads a family's rows from there as it goes.
+//     double, one fused multiply-add per family and state (hard_loop_first, which stages its
+//     chunk's rows in LDS once per block and computes a dot product with a family's row for both
+//     common forms at once - the rows are the same for all lanes - every observation keeping the
+//     result of its own form);
+//   * the dot products of the later launches' normalisers are matrix products of the parent's P'
+//     (128 observations x states) with the families' rows of 1 / q (hard_loop_light);
+//   * the count sums factor into sums by evidence form, which are matrix products of the parent's
+//     posterior with the 0 / 1 pattern of the state bytes (hard_reduce_mfma).
 //
 //   hard_loop_first   the call's first iteration on fresh messages: what leaf_loop_p1 does in its
 //                     fresh / ingesting state (prod q per state, prod z of iterations 1 and 2)
 //   hard_loop_light   a later loop iteration: prod z of the next iteration from the parent's P'
-//   hard_reduce_mfma  the last iteration of a statistics call, with the normalisers of the iteration
-//                     before recomputed (leaf_family_p1 in reduce mode, kLeafRecompute)
-// Float plans, two-state leaves, parents of at most 16 states, two observations per lane, the
-// leaves' state rows at equal distances in memory (LeafFamilyArgs::src_base / src_stride).
+//   hard_reduce_mfma  the last iteration of a statistics call: the count sums (the leaves'
+//                     normalisers are those of the last hard_loop_light launch)
+// Float plans, two-state leaves, parents of at most 16 states, the leaves' state rows at equal
+// distances in memory (LeafFamilyArgs::src_base / src_stride), an even number of observations.
 #pragma once
 
 #include "kernels_leaf.h"
@@ -243,39 +242,6 @@ __device__ __forceinline__ fv<float, 2> hard_dot_own(const fv<float, 2>* x, cons
   return out;
 }
 
-// hard_dot_own for two families at once: four independent chains of fused multiply-adds, so that no
-// instruction has to wait for the one before it (a packed multiply-add that depends on its
-// predecessor costs a wait state)
-template <int D0>
-__device__ __forceinline__ void hard_dot_own2(const fv<float, 2>* x, const float* tab, int32_t k_a, int32_t k_b, int32_t third_row,
-                                              const HardRows<D0>& ra, const HardRows<D0>& rb, const HardForms& fa,
-                                              const HardForms& fb, bool any_third, fv<float, 2>* out_a, fv<float, 2>* out_b) {
-  fv<float, 2> a0 = splat<float, 2>(0.f), a1 = a0, b0 = a0, b1 = a0;
-#pragma unroll
-  for (int32_t d = 0; d < D0; ++d) {
-    a0 = __builtin_elementwise_fma(x[d], splat<float, 2>(ra.r0.x[d]), a0);
-    b0 = __builtin_elementwise_fma(x[d], splat<float, 2>(rb.r0.x[d]), b0);
-    a1 = __builtin_elementwise_fma(x[d], splat<float, 2>(ra.r1.x[d]), a1);
-    b1 = __builtin_elementwise_fma(x[d], splat<float, 2>(rb.r1.x[d]), b1);
-  }
-#pragma unroll
-  for (int32_t v = 0; v < 2; ++v) {
-    (*out_a)[v] = fa.one[v] ? a1[v] : a0[v];
-    (*out_b)[v] = fb.one[v] ? b1[v] : b0[v];
-  }
-  if (any_third) {
-    HardRow<D0> r2a, r2b;
-    r2a.load(tab, k_a, third_row);
-    r2b.load(tab, k_b, third_row);
-    const fv<float, 2> sa = hard_dot<D0>(x, r2a), sb = hard_dot<D0>(x, r2b);
-#pragma unroll
-    for (int32_t v = 0; v < 2; ++v) {
-      (*out_a)[v] = fa.third[v] ? sa[v] : (*out_a)[v];
-      (*out_b)[v] = fb.third[v] ? sb[v] : (*out_b)[v];
-    }
-  }
-}
-
 template <int D0>
 __device__ __forceinline__ void hard_load_scaled(const double* scaled, int64_t npad, int64_t obs0, fv<float, 2>* pf) {
 #pragma unroll
@@ -302,7 +268,7 @@ __device__ __forceinline__ void hard_store_divisor(double* mant, int32_t* exp, i
 // families whose state bytes are in flight per wave: a request is 128 bytes only, so it takes many of
 // them to cover the memory latency
 // (the loops are unrolled over one ring; a second ring behind it doubles the distance)
-constexpr int32_t kHardRingFirst = 4, kHardRingLight = 8, kHardRing = 8;
+constexpr int32_t kHardRingFirst = 4;
 
 // ---------------------------------------------------------------------------------
 // The per-state product of the q over the chunk's families is carried as a sum of logarithms in

@@ -62,7 +62,7 @@ LeafLoopRef pack_loop(int32_t dtype, int32_t out, int32_t from, int32_t s, int32
 HardKernelRefs pack_hard() {
   const HardKernels k = hard_kernels_for<D0>();
   return {reinterpret_cast<const void*>(k.first), reinterpret_cast<const void*>(k.light),
-          reinterpret_cast<const void*>(k.reduce), reinterpret_cast<const void*>(k.tables), k.first_lds, k.rows_lds};
+          reinterpret_cast<const void*>(k.reduce), reinterpret_cast<const void*>(k.tables), k.first_lds};
 }
 
 WideKernelRefs pack_wide(int32_t dtype) { return dtype == 0 ? wide_kernels_for<float, D0>() : wide_kernels_for<double, D0>(); }

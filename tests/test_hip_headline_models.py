@@ -550,6 +550,38 @@ def test_whole_step_on_state_bytes_read_in_place(kind, n):
     assert by_bytes.log_likelihood() == fresh.log_likelihood()
 
 
+@pytest.mark.parametrize("iterations", [1, 2, 3, 4, 5, 6])
+def test_state_bytes_step_at_iteration_counts_around_the_diameter(iterations):
+    """The launches of a step on state bytes depend on the number of iterations: the reduce launch
+    takes the leaves' normalisers from the last light loop launch, so with three iterations the loop
+    launch before it is not left out, with one or two the float kernels serve the step.  Against the
+    step on the float tensors the bytes stand for, run for the same number of iterations."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+
+    n = 2050
+    ts, network, ys = _leaf_model("c3a", "float32", "cuda")
+    gen = torch.Generator().manual_seed(5)
+    states = (torch.rand((len(ys), n), generator=gen) < 0.4).to(torch.uint8)
+    hard = HardEvidence(states.cuda(), [2] * len(ys), ts, on_value=0.999999 + 5e-7, off_value=5e-7)
+    hard.states[3, 2049] = 9
+    tensors = [t.clone() for t in hard.data]
+    settings = SpaInferenceMachineSettings(ts, False, num_iterations=iterations)
+    model = FlatModel.of(network)
+    model.assign(model.gather())
+
+    def machine_for():
+        machine = HipSpaInferenceMachine(settings, network, ys, n)
+        machine.enable_star_step(False)
+        return machine
+
+    ll_f, counts_f = machine_for().em_step_statistics(Evidence(tensors, ts))
+    ll_h, counts_h = machine_for().em_step_statistics(hard)
+    assert abs(ll_h.item() - ll_f.item()) <= 2e-6 * abs(ll_f.item())
+    np.testing.assert_allclose(counts_h.cpu().numpy(), counts_f.cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
 @pytest.mark.parametrize("iterations", [1, 2, 3, 5, 6])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_784_leaf_model_at_iteration_counts_around_the_diameter(iterations, dtype):
