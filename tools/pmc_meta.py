@@ -16,7 +16,7 @@ signatures = {k["kernel"]: k.get("signature") for k in bench.get("kernels", [])}
 for entry in bench.get("secondary", []) or []:
     roof = entry.get("roofline") or {}
     if roof.get("kernel"):
-        signatures[roof["kernel"]] = roof.get("signature")
+        signatures.setdefault(roof["kernel"], roof.get("signature"))  # (a label of the line's own kernels stays theirs)
 meta = dict(git=os.environ.get("BN_GIT_HEAD"), signatures=signatures)
 for path in sys.argv[2:]:
     data = json.load(open(path))
