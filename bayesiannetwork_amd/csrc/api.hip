@@ -70,6 +70,15 @@ struct bn_plan {
   int64_t star_failures = 0;  // ... of which so many were found void (their blocks could not synchronise)
   uint32_t* finish_counter = nullptr;  // arrival counter of em_finish (kernels_finish.h), zero between launches
   int32_t finish_shape = 0;            // 0 not examined yet, 1 the plan's steps can end in em_finish, -1 they cannot
+  // Float evidence of a whole-step call that turns out to be hard evidence in disguise - every row one of
+  // (a, b) and (b, a) - is turned into state bytes first (compact_evidence): the step then reads 47 MB
+  // per launch instead of 376.  bn_plan_enable_evidence_compaction
+  bool compact_wanted = true;
+  uint8_t* compact_states = nullptr;  // [observed][N] state bytes, then the kernel's verdict (CompactVerdict)
+  void* compact_verdict_host = nullptr;  // pinned: where the verdict is copied for the host to read
+  int32_t compact_skip = 0;           // calls to go before evidence that was not of that kind is looked at again
+  float compact_rows[6] = {};         // what the state bytes of the last compaction stand for (HardEvidenceRows)
+  int64_t compactions = 0;            // whole-step calls that ran on state bytes made this way
 };
 
 namespace {
@@ -1353,6 +1362,8 @@ int bn_plan_destroy(bn_plan* plan) {
   if (plan->capture_stream) (void)hipStreamDestroy(plan->capture_stream);
   if (plan->accum_slot) (void)hipFree(plan->accum_slot);
   if (plan->finish_counter) (void)hipFree(plan->finish_counter);
+  if (plan->compact_states) (void)hipFree(plan->compact_states);
+  if (plan->compact_verdict_host) (void)hipHostFree(plan->compact_verdict_host);
   bn::release_fast(plan->p);
   release(plan->p);
   (void)hipSetDevice(prev);
@@ -1410,6 +1421,14 @@ int32_t bn_two_parent_shape_served(int32_t d0, int32_t d1, int32_t s) {
 }
 
 const char* bn_cardinality_pack_directory(void) { return bn::cardinality_pack_directory(); }
+
+int bn_plan_enable_evidence_compaction(bn_plan* plan, int32_t enabled) {
+  if (!plan) return fail(BN_ERR_INVALID, "plan is null");
+  plan->compact_wanted = enabled != 0;
+  return BN_OK;
+}
+
+int64_t bn_plan_evidence_compactions(const bn_plan* plan) { return plan ? plan->compactions : 0; }
 
 int bn_plan_enable_star_step(bn_plan* plan, int32_t enabled) {
   if (!plan) return fail(BN_ERR_INVALID, "plan is null");
@@ -1842,11 +1861,102 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
   return rc;
 }
 
+// Float evidence of a whole-step call that is hard evidence in disguise: the rows of all leaves and observations
+// are two rows only, one per state (what expanding states with an on and an off value gives, or clamping
+// one-hot rows).
+// Then the step runs on state bytes (kernels_hard.h), which this turns the arrays into first: one pass
+// over the evidence (evidence_two_rows) and a look at its verdict, which costs less than the two
+// passes over the float arrays it saves from batches of kCompactMinN observations on.  *states: the
+// state bytes (plan->compact_rows: what they stand for), or null when the evidence is not of that kind
+// (or the step would not run on them).
+constexpr int64_t kCompactMinN = 32768;
+int compact_evidence(bn_plan* plan, const void* const* evidence_dev, int32_t num_iterations, hipStream_t s,
+                     const uint8_t** states) {
+  *states = nullptr;
+  bn::Plan& p = plan->p;
+  static const bool off = getenv("BN_NO_EVIDENCE_COMPACTION") != nullptr;
+  static const int64_t min_n = getenv("BN_COMPACT_MIN_N") ? atoll(getenv("BN_COMPACT_MIN_N")) : kCompactMinN;
+  if (off || !plan->compact_wanted || p.dtype != BN_F32 || p.observed.empty() || !evidence_dev || num_iterations < 3 ||
+      p.N < min_n || p.N % 2 != 0 || !bn::ingest_states_possible(p))
+    return BN_OK;
+  if (step_graphs_enabled() && plan->graphs_wanted && !plan->graphs_off) return BN_OK;  // (captured steps keep their route)
+  if (plan->compact_skip > 0) {
+    --plan->compact_skip;
+    return BN_OK;
+  }
+  // the arrays at equal distances, in the order of the observed nodes
+  const size_t K = p.observed.size();
+  const char* base = static_cast<const char*>(evidence_dev[0]);
+  const int64_t stride = K > 1 ? static_cast<const char*>(evidence_dev[1]) - base : (int64_t)p.N * 8;
+  for (size_t i = 0; i < K; ++i)
+    if (!evidence_dev[i] || static_cast<const char*>(evidence_dev[i]) != base + (int64_t)i * stride) return BN_OK;
+  if (reinterpret_cast<uintptr_t>(base) % 16 != 0 || stride % 16 != 0) return BN_OK;  // (the kernel reads 16 bytes at a time)
+  constexpr int32_t kBlocks = 1024;  // of the pass over the evidence: four per compute unit
+  if (!plan->compact_states) {
+    const size_t bytes = K * (size_t)p.N + 64 + kBlocks * sizeof(bn::CompactVerdict);
+    BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&plan->compact_states), bytes));
+    // pinned: where the blocks' verdicts are copied for the host to read
+    BN_HIP_CHECK(hipHostMalloc(&plan->compact_verdict_host, kBlocks * sizeof(bn::CompactVerdict), hipHostMallocDefault));
+    p.device_bytes += (int64_t)bytes;
+  }
+  // would the step run on them?  (the families' rows as the state bytes would give them)
+  if (int rc = upload_family_sources(p, nullptr, s, plan->compact_states, true)) return rc;
+  if (!bn::caller_states_possible(p, num_iterations)) {
+    plan->compact_wanted = false;  // a property of the plan: not asked again
+    return BN_OK;
+  }
+  bn::CompactVerdict* host = static_cast<bn::CompactVerdict*>(plan->compact_verdict_host);
+  bn::CompactVerdict* verdict = reinterpret_cast<bn::CompactVerdict*>(plan->compact_states + (K * (size_t)p.N + 63) / 64 * 64);
+  prof_begin("evidence_compaction", (double)K * (double)p.N * 9.0, s);
+  const int64_t quads = (int64_t)K * ((p.N + 3) / 4);
+  const int32_t blocks = (int32_t)std::min<int64_t>(kBlocks, (quads + 255) / 256);
+  bn::launch(bn::evidence_two_rows, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const float*>(base), stride / 4,
+             p.N, (int64_t)K, plan->compact_states, verdict);
+  BN_LAUNCH_CHECK("evidence_two_rows");
+  prof_end(s);
+  BN_HIP_CHECK(hipMemcpyAsync(host, verdict, (size_t)blocks * sizeof(bn::CompactVerdict), hipMemcpyDeviceToHost, s));
+  BN_HIP_CHECK(hipStreamSynchronize(s));
+  bn::CompactVerdict seen{};
+  for (int32_t i = 0; i < 4; ++i) seen.lo[i] = 0x7f800000u;
+  for (int32_t b = 0; b < blocks; ++b) {
+    seen.other |= host[b].other;
+    for (int32_t i = 0; i < 4; ++i) {
+      seen.lo[i] = std::min(seen.lo[i], host[b].lo[i]);
+      seen.hi[i] = std::max(seen.hi[i], host[b].hi[i]);
+    }
+  }
+  bool two_rows = seen.other == 0;
+  for (int32_t i = 0; i < 4; ++i) two_rows = two_rows && (seen.lo[i] == seen.hi[i] || seen.lo[i] > seen.hi[i]);
+  if (!two_rows) {
+    plan->compact_skip = 63;  // evidence of another kind: the next batches are taken as they come
+    return BN_OK;
+  }
+  // the rows of the two states (a state no observation has takes the other's: nothing reads it), and for a
+  // state byte beyond them - there is none - the smaller entries
+  auto value = [](uint32_t bits) {
+    float x;
+    std::memcpy(&x, &bits, sizeof x);
+    return x;
+  };
+  const bool has0 = seen.lo[0] <= seen.hi[0], has1 = seen.lo[2] <= seen.hi[2];
+  if (!has0 && !has1) return BN_OK;
+  float* rows = plan->compact_rows;
+  for (int32_t st = 0; st < 2; ++st) {
+    const int32_t from = (st == 0 ? has0 : has1) ? st : 1 - st;
+    rows[2 * st] = value(seen.lo[2 * from]);
+    rows[2 * st + 1] = value(seen.lo[2 * from + 1]);
+  }
+  rows[4] = rows[5] = std::min(std::min(rows[0], rows[1]), std::min(rows[2], rows[3]));
+  *states = plan->compact_states;
+  ++plan->compactions;
+  return BN_OK;
+}
+
 // Evidence of a whole-step call (bn_em_step, bn_em_step_statistics): read by the first iteration itself
 // where bn_em_statistics_from[_states] would do so, and - the plan being reset when the call ends - by
 // every launch from the caller's arrays where the kernels for that exist (no copy at all).
 static int step_evidence(bn_plan* plan, const void* const* evidence_dev, const uint8_t* states_dev, double on_value,
-                  double off_value, int32_t num_iterations, void* stream) {
+                  double off_value, int32_t num_iterations, void* stream, const float* rows = nullptr) {
   bn::Plan& p = plan->p;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bool ingest = !p.observed.empty() && num_iterations >= 3 && p.N >= 2 && p.N % 2 == 0;
@@ -1868,7 +1978,10 @@ static int step_evidence(bn_plan* plan, const void* const* evidence_dev, const u
     if (states_dev) {
       bn::set_ingest_next(p, true, true, on_value, off_value);
       // ... and neither would anything read a copy of the state bytes
-      bn::set_states_in_caller(p, bn::caller_states_possible(p, num_iterations), on_value, off_value);
+      if (rows)  // (state bytes made from float evidence: compact_evidence has made sure the step runs on them)
+        bn::set_states_in_caller(p, bn::caller_states_possible(p, num_iterations), rows);
+      else
+        bn::set_states_in_caller(p, bn::caller_states_possible(p, num_iterations), on_value, off_value);
     } else {
       bn::set_ingest_next(p, true);
       // the plan is reset when the step ends: nothing would ever read its copy of the evidence
@@ -1934,7 +2047,14 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
       plan->star.ok = false;  // the runtime refused the cooperative launch: launch per pass from now on
     }
   }
-  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream)) return rc;
+  const uint8_t* compacted = nullptr;  // state bytes made from float evidence (they stand for plan->compact_rows)
+  if (!states_dev) {
+    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted)) return rc;
+    states_dev = compacted;
+  }
+  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream,
+                             compacted ? plan->compact_rows : nullptr))
+    return rc;
   if (!plan->accum_slot) {
     BN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&plan->accum_slot), (size_t)std::max<int64_t>(p.cpt_total, 1) * sizeof(double)));
     p.device_bytes += p.cpt_total * 8;
@@ -2024,7 +2144,14 @@ int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const 
     ~NoGraphs() { plan->graphs_off = before; }
   } no_graphs{plan, plan->graphs_off};
   plan->graphs_off = true;
-  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream)) return rc;
+  const uint8_t* compacted = nullptr;  // state bytes made from float evidence (they stand for plan->compact_rows)
+  if (!states_dev) {
+    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted)) return rc;
+    states_dev = compacted;
+  }
+  if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream,
+                             compacted ? plan->compact_rows : nullptr))
+    return rc;
   int32_t ll_blocks = 0;
   const double ll_scale = average ? 1.0 / (double)p.N : 1.0;
   t_discard_last_messages = true;

@@ -16,7 +16,7 @@
 
 namespace bn {
 
-constexpr int32_t kPackAbi = 2;  // bumped whenever a kernel's arguments or this table change
+constexpr int32_t kPackAbi = 3;  // bumped whenever a kernel's arguments or this table change
 
 struct LeafLoopRef {
   const void* fn;

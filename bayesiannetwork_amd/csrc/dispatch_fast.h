@@ -162,12 +162,16 @@ inline bool caller_states_possible(const Plan& p, int32_t num_iterations) {
   return !st->fused.empty();
 }
 
-inline void set_states_in_caller(Plan& p, bool on, double on_value = 1.0, double off_value = 0.0) {
+// rows: what the three forms of the state bytes stand for (6 floats: kernels_leaf.h, HardEvidenceRows)
+inline void set_states_in_caller(Plan& p, bool on, const float* rows = nullptr) {
   if (FastState* st = fast_state(p)) {
     st->states_in_caller = on;
-    st->states_on = on_value;
-    st->states_off = off_value;
+    if (rows) std::copy(rows, rows + 6, st->states_rows);
   }
+}
+inline void set_states_in_caller(Plan& p, bool on, double on_value, double off_value) {
+  const float rows[6] = {(float)on_value, (float)off_value, (float)off_value, (float)on_value, (float)off_value, (float)off_value};
+  set_states_in_caller(p, on, rows);
 }
 
 inline void set_ingest_next(Plan& p, bool on, bool from_states = false, double on_value = 1.0, double off_value = 0.0) {
@@ -1035,8 +1039,7 @@ inline void append_state_signature(const Plan& p, std::string& key) {
   put(st->ingest_next);
   put(st->evidence_in_caller);
   put(st->states_in_caller);
-  put(st->states_on);
-  put(st->states_off);
+  put(st->states_rows);
   put(st->ingest_states);
   put(st->ingest_on);
   put(st->ingest_off);
@@ -1108,8 +1111,11 @@ inline int ll_partials_reduced(Plan& p, double* partial, int32_t max_blocks, hip
 // how the last reduce-mode launch of a fused group left its count sums
 inline FormSums form_sums_of(const Plan& p, const FusedFamily& fam) {
   FastState* st = fast_state(p);
-  if (!fam.em_by_form) return FormSums{nullptr, 0.f, 0.f};
-  return FormSums{static_cast<const float*>(fam.z_state), (float)st->states_on, (float)st->states_off};
+  FormSums forms{};
+  if (!fam.em_by_form) return forms;
+  forms.tab = static_cast<const float*>(fam.z_state);
+  std::copy(st->states_rows, st->states_rows + 6, forms.rows.e);
+  return forms;
 }
 
 // EM counts of a fused group straight from the reduce-mode sums, if they describe the current state.

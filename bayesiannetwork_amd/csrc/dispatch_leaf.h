@@ -216,8 +216,7 @@ inline int launch_hard_family(Plan& p, FactorGroup& g, FusedFamily& fam, WideNod
   a.ll_part = fam.ll_part;
   a.src_base = fam.src_base;
   a.src_stride = fam.src_stride;
-  a.on_value = (float)fast_state(p)->states_on;
-  a.off_value = (float)fast_state(p)->states_off;
+  std::copy(fast_state(p)->states_rows, fast_state(p)->states_rows + 6, a.hard_rows.e);
   HardFn fn = nullptr;
   size_t lds_bytes = 0;
   if (mode == kLeafLoop) {

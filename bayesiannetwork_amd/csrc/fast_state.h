@@ -151,7 +151,8 @@ struct FastState {
   bool evidence_in_caller = false;
   // ... and the same for compact hard evidence: every launch reads the caller's state bytes (kernels_hard.h)
   bool states_in_caller = false;
-  double states_on = 1.0, states_off = 0.0;  // what the state bytes stand for, for the whole step
+  // what the state bytes stand for, for the whole step: row entry j of form y at [2 y + j] (kernels_leaf.h, HardEvidenceRows)
+  float states_rows[6] = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
 };
 
 // The plan owns its FastState through Plan::fast (opaque there, so that plan.h needs no kernel types).

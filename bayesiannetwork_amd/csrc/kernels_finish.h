@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(256) em_finish(FinishArgs<T> a) {
         const double g1 = counts[1] + hard_third_sum(a.forms.tab, a.K, a.D0, k, 1, d);
 #pragma unroll
         for (int32_t j = 0; j < 2; ++j)
-          counts[j] = hard_count(g0, g1, rec[kHardRq * a.D0 + d], rec[(kHardRq + 1) * a.D0 + d], j, a.forms.on,
-                                 a.forms.off, (double)a.cpts[off + j]);
+          counts[j] = hard_count(g0, g1, rec[kHardRq * a.D0 + d], rec[(kHardRq + 1) * a.D0 + d], j, a.forms.rows,
+                                 (double)a.cpts[off + j]);
       } else {
 #pragma unroll
         for (int32_t j = 0; j < 4; ++j)

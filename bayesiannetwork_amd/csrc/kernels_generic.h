@@ -246,6 +246,91 @@ __global__ void __launch_bounds__(64) factor_pass_generic(T* __restrict__ arena,
   }
 }
 
+// Is float evidence of two-state leaves hard evidence in disguise - does every leaf's every observation
+// have one of two rows?  A row counts for the state whose entry is the larger one (state 1 when they are
+// equal) and its state is written to states[leaf][n]; the rows of a state are all the same exactly when
+// the smallest and the largest value seen of either entry coincide, which is what the verdicts hold, one
+// per block of the launch (as bit patterns: the entries must not be negative, or `other` is set).  ev: the first leaf's array
+// ([N][2], 16-byte aligned), the others leaf_stride floats apart (a multiple of four); N even.  A thread takes four
+// observations at a time, a grid of any size the lot.
+struct CompactVerdict {
+  int32_t other;           // some entry is negative or not a number
+  uint32_t lo[4], hi[4];   // of (state 0: entry 0, entry 1; state 1: entry 0, entry 1); lo > hi: no such row
+  int32_t pad[7];
+};
+static __global__ void __launch_bounds__(256) evidence_two_rows(const float* __restrict__ ev, int64_t leaf_stride, int64_t N,
+                                                        int64_t leaves, uint8_t* __restrict__ states, CompactVerdict* verdict) {
+  const int64_t quads_per_leaf = (N + 3) / 4;
+  const int64_t total = leaves * quads_per_leaf;
+  uint32_t lo[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u}, hi[4] = {0u, 0u, 0u, 0u};
+  bool other = false;
+  for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < total; item += (int64_t)gridDim.x * 256) {
+    const int64_t leaf = item / quads_per_leaf, n0 = (item - leaf * quads_per_leaf) * 4;
+    const float* rows = ev + leaf * leaf_stride + n0 * 2;
+    const bool whole = n0 + 4 <= N;  // (else two observations are left: N is even)
+    const float4 first = *reinterpret_cast<const float4*>(rows);
+    const float4 second = whole ? *reinterpret_cast<const float4*>(rows + 4) : first;
+    const float x[4] = {first.x, first.z, second.x, second.z}, y[4] = {first.y, first.w, second.y, second.w};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int32_t v = 0; v < 4; ++v) {
+      other |= !(x[v] >= 0.f && y[v] >= 0.f);
+      const uint32_t state = x[v] > y[v] ? 0u : 1u;
+      packed |= state << (8 * v);
+      const uint32_t bx = __builtin_bit_cast(uint32_t, x[v]), by = __builtin_bit_cast(uint32_t, y[v]);
+#pragma unroll
+      for (int32_t st = 0; st < 2; ++st) {
+        const bool mine = state == (uint32_t)st;
+        lo[2 * st] = mine && bx < lo[2 * st] ? bx : lo[2 * st];
+        hi[2 * st] = mine && bx > hi[2 * st] ? bx : hi[2 * st];
+        lo[2 * st + 1] = mine && by < lo[2 * st + 1] ? by : lo[2 * st + 1];
+        hi[2 * st + 1] = mine && by > hi[2 * st + 1] ? by : hi[2 * st + 1];
+      }
+    }
+    if (whole)
+      *reinterpret_cast<uint32_t*>(states + leaf * N + n0) = packed;
+    else
+      *reinterpret_cast<uint16_t*>(states + leaf * N + n0) = (uint16_t)packed;
+  }
+  // the wave's extremes, then the block's: every block leaves a verdict of its own (atomics of a few thousand
+  // waves on the same eight words took 1.5 ms)
+  __shared__ uint32_t part[4][9];
+#pragma unroll
+  for (int32_t i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int32_t o = 32; o > 0; o >>= 1) {
+      const uint32_t l = __shfl_xor(lo[i], o, 64), h = __shfl_xor(hi[i], o, 64);
+      lo[i] = l < lo[i] ? l : lo[i];
+      hi[i] = h > hi[i] ? h : hi[i];
+    }
+  }
+  other = __any((int)other) != 0;
+  const int32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int32_t i = 0; i < 4; ++i) {
+      part[wave][i] = lo[i];
+      part[wave][4 + i] = hi[i];
+    }
+    part[wave][8] = other ? 1u : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    CompactVerdict mine{};
+#pragma unroll
+    for (int32_t i = 0; i < 4; ++i) {
+      mine.lo[i] = 0x7f800000u;
+      for (int32_t wv = 0; wv < 4; ++wv) {
+        mine.lo[i] = part[wv][i] < mine.lo[i] ? part[wv][i] : mine.lo[i];
+        mine.hi[i] = part[wv][4 + i] > mine.hi[i] ? part[wv][4 + i] : mine.hi[i];
+      }
+    }
+    for (int32_t wv = 0; wv < 4; ++wv) mine.other |= (int32_t)part[wv][8];
+    verdict[blockIdx.x] = mine;
+  }
+}
+
+
 // ---------------------------------------------------------------------------------
 // Evidence: ev[n, s] (row-major, caller's buffer) -> observation array in tile layout.
 // Pure copy, bit-exact (VariableNodeGroup.set_observations, spa_v3/factor_graph.py:166-170).

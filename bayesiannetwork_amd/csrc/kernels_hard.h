@@ -102,19 +102,23 @@ __global__ void __launch_bounds__(256) hard_tables_build(const float* __restrict
   float rq[kHardForms], qs[kHardForms];
 #pragma unroll
   for (int32_t y = 0; y < kHardForms; ++y) {
-    float q = cpt[d * 2] * hard_ev(y, 0, a.on_value, a.off_value);
-    q = fmaf(cpt[d * 2 + 1], hard_ev(y, 1, a.on_value, a.off_value), q);
+    float q = cpt[d * 2] * hard_ev(a.hard_rows, y, 0);
+    q = fmaf(cpt[d * 2 + 1], hard_ev(a.hard_rows, y, 1), q);
     qs[y] = q;
     rq[y] = fast_rcp(q);
     rec[(kHardQ + y) * D0] = q;
     rec[(kHardRq + y) * D0] = rq[y];
   }
-  // x0, x1 with  rq0 * on * x0 + rq1 * off * x1 = rq0 * off * x0 + rq1 * on * x1 = rq2 * off
-  const double on = a.on_value, off = a.off_value;
-  const double target = (double)rq[2] * off;
-  const bool same = on == off;
-  rec[(kHardThird + 0) * D0] = (float)(same ? 1.0 : target / ((double)rq[0] * (on + off)));
-  rec[(kHardThird + 1) * D0] = (float)(same ? 0.0 : target / ((double)rq[1] * (on + off)));
+  // x0, x1 with  rq0 * ev(0)[j] * x0 + rq1 * ev(1)[j] * x1 = rq2 * ev(2)[j]  for both j
+  {
+    const double e00 = hard_ev(a.hard_rows, 0, 0), e01 = hard_ev(a.hard_rows, 0, 1), e10 = hard_ev(a.hard_rows, 1, 0),
+                 e11 = hard_ev(a.hard_rows, 1, 1);
+    const double t0 = (double)rq[2] * hard_ev(a.hard_rows, 2, 0), t1 = (double)rq[2] * hard_ev(a.hard_rows, 2, 1);
+    const double det = e00 * e11 - e10 * e01;
+    const bool none = det == 0.0;  // (the two forms' rows in line: an observation of the third form counts for form 0)
+    rec[(kHardThird + 0) * D0] = (float)(none ? 1.0 : (t0 * e11 - t1 * e10) / (det * (double)rq[0]));
+    rec[(kHardThird + 1) * D0] = (float)(none ? 0.0 : (t1 * e00 - t0 * e01) / (det * (double)rq[1]));
+  }
   double* logs = reinterpret_cast<double*>(tab + (size_t)k * (kHardRows * D0) + (size_t)kHardLog * D0) + d;
   double lg[kHardForms];
 #pragma unroll
@@ -370,8 +374,8 @@ __global__ void __launch_bounds__(256) hard_loop_first(const float* __restrict__
     double lz[kHardForms];
 #pragma unroll
     for (int32_t y = 0; y < kHardForms; ++y) {
-      float z = hard_ev(y, 0, a.on_value, a.off_value) * (1.0f / (float)S);
-      z = fmaf(hard_ev(y, 1, a.on_value, a.off_value), 1.0f / (float)S, z);
+      float z = hard_ev(a.hard_rows, y, 0) * (1.0f / (float)S);
+      z = fmaf(hard_ev(a.hard_rows, y, 1), 1.0f / (float)S, z);
       lz[y] = z > 0.f ? log2((double)z) : kHardLogOfZero;
     }
     double2 m;

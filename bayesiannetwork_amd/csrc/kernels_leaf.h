@@ -8,6 +8,13 @@ namespace bn {
 
 // ---------------------------------------------------------------------------------
 // Leaf families with one (wide) parent: see the file header.
+// The evidence rows the three forms of compact hard evidence stand for: e[2 y + j] = row entry j of an
+// observation of form y (0, 1: the leaf's states; 2: neither).  State bytes given with an on and an off
+// value: (on, off), (off, on), (off, off).
+struct HardEvidenceRows {
+  float e[6];
+};
+
 template <typename T>
 struct LeafFamilyArgs {
   const int64_t* f_in;     // [K*arity]  v2f offsets of the factor group (parent slots, own slot)
@@ -54,6 +61,7 @@ struct LeafFamilyArgs {
   // compact hard evidence read in place (kernels_hard.h): the step's tables of q and 1 / q per evidence form
   const float* hard_tab;
   T on_value, off_value;  // evidence given as states: what an observed / any other state's row receives
+  HardEvidenceRows hard_rows;  // ... and the rows of the forms of compact hard evidence read in place (kernels_hard.h)
   // leaf_loop_p1 only: 1, or kWavesPerBlock when the waves of a block share one (chunk, tile, part)
   // work item, each taking a quarter of the chunk's families (small batches: as many waves as
   // before, a quarter of the chunk partials for the parent's combine to read)
@@ -993,7 +1001,7 @@ struct ListedEntries {
 // tab == nullptr: sums by entry.
 struct FormSums {
   const float* tab;
-  float on, off;
+  HardEvidenceRows rows;  // what the evidence forms stand for
 };
 
 constexpr int32_t kHardForms = 3;  // evidence forms of a two-state leaf: state 0, state 1, neither
@@ -1007,7 +1015,7 @@ constexpr int32_t kHardRows = 14, kHardQ = 0, kHardRq = 3, kHardThird = 6, kHard
 constexpr double kHardLogOfZero = -1.0e6;
 
 // evidence row j of a two-state leaf whose evidence has form y (0, 1; 2: neither state)
-__device__ __forceinline__ float hard_ev(int32_t y, int32_t j, float on, float off) { return y == j ? on : off; }
+__device__ __forceinline__ float hard_ev(const HardEvidenceRows& rows, int32_t y, int32_t j) { return rows.e[2 * y + j]; }
 
 // counts[d][j] of a family from its sums by form, G[y][d] = sum over the observations of form y of
 // P'[d] * scale:  cpt[d][j] * (ev(0)[j] * G[0][d] / q[0][d] + ev(1)[j] * G[1][d] / q[1][d])
@@ -1016,11 +1024,11 @@ __device__ __forceinline__ double hard_third_sum(const float* tab, int32_t K, in
   return (double)tab[(size_t)K * (kHardRows * d0) + (size_t)k * (2 * d0) + (size_t)y * d0 + d];
 }
 
-__device__ __forceinline__ double hard_count(double g0, double g1, float rq0, float rq1, int32_t j, float on, float off,
+__device__ __forceinline__ double hard_count(double g0, double g1, float rq0, float rq1, int32_t j, const HardEvidenceRows& rows,
                                              double cpt) {
 #pragma clang fp contract(off)
-  const double x0 = ((double)rq0 * (double)hard_ev(0, j, on, off)) * g0;
-  const double x1 = ((double)rq1 * (double)hard_ev(1, j, on, off)) * g1;
+  const double x0 = ((double)rq0 * (double)hard_ev(rows, 0, j)) * g0;
+  const double x1 = ((double)rq1 * (double)hard_ev(rows, 1, j)) * g1;
   return (x0 + x1) * cpt;
 }
 
@@ -1065,8 +1073,8 @@ __global__ void __launch_bounds__(256) em_finalize_slots(const T* __restrict__ e
     const double g1 = slot_sum(item - j + 1) + hard_third_sum(forms.tab, K, d0, k, 1, d);
     const float* rec = forms.tab + (size_t)k * (kHardRows * d0);
     if (lane == 0)
-      accum[cpt_off[k] + e] = hard_count(g0, g1, rec[kHardRq * d0 + d], rec[(kHardRq + 1) * d0 + d], j, forms.on,
-                                         forms.off, (double)cpts[cpt_off[k] + e]);
+      accum[cpt_off[k] + e] = hard_count(g0, g1, rec[kHardRq * d0 + d], rec[(kHardRq + 1) * d0 + d], j, forms.rows,
+                                         (double)cpts[cpt_off[k] + e]);
     return;
   }
   const double acc = slot_sum(item);

@@ -59,6 +59,10 @@ def _declare(lib):
     lib.bn_plan_enable_step_graphs.argtypes = [c_void_p, c_int32]
     lib.bn_plan_enable_star_step.restype = c_int
     lib.bn_plan_enable_star_step.argtypes = [c_void_p, c_int32]
+    lib.bn_plan_enable_evidence_compaction.restype = c_int
+    lib.bn_plan_enable_evidence_compaction.argtypes = [c_void_p, c_int32]
+    lib.bn_plan_evidence_compactions.restype = c_int64
+    lib.bn_plan_evidence_compactions.argtypes = [c_void_p]
     lib.bn_plan_star_step_launches.restype = c_int64
     lib.bn_plan_star_step_launches.argtypes = [c_void_p]
     lib.bn_plan_star_step_failures.restype = c_int64
@@ -145,7 +149,7 @@ def _declare(lib):
 EXPORTS = (
     "bn_abi_version", "bn_last_error", "bn_plan_create", "bn_plan_destroy", "bn_plan_topology",
     "bn_plan_cpt_elements", "bn_plan_device_bytes", "bn_plan_unmapped_bytes", "bn_plan_map_message_arrays", "bn_plan_enable_step_graphs",
-    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_star_step_launches", "bn_plan_star_step_failures", "bn_star_barrier_verdict", "bn_cardinality_served", "bn_two_parent_shape_served", "bn_cardinality_pack_directory", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
+    "bn_plan_step_graph_launches", "bn_plan_enable_star_step", "bn_plan_enable_evidence_compaction", "bn_plan_evidence_compactions", "bn_plan_star_step_launches", "bn_plan_star_step_failures", "bn_star_barrier_verdict", "bn_cardinality_served", "bn_two_parent_shape_served", "bn_cardinality_pack_directory", "bn_em_step", "bn_em_step_statistics", "bn_set_cpts", "bn_reset_messages",
     "bn_enter_evidence", "bn_enter_evidence_states", "bn_iterate", "bn_log_likelihood", "bn_local_log_likelihoods",
     "bn_marginal_single", "bn_marginal_family", "bn_em_accumulate", "bn_em_statistics", "bn_em_statistics_static", "bn_em_statistics_from", "bn_em_statistics_from_states", "bn_m_step", "bn_normaliser_change", "bn_get_message",
     "bn_exact_create", "bn_exact_destroy", "bn_exact_set_cpts", "bn_exact_enter_evidence",

@@ -550,6 +550,65 @@ def test_whole_step_on_state_bytes_read_in_place(kind, n):
     assert by_bytes.log_likelihood() == fresh.log_likelihood()
 
 
+def test_float_evidence_that_is_hard_evidence_runs_on_state_bytes():
+    """``em_step`` / ``em_step_statistics`` look at float evidence of large batches first: when every row is
+    one of two rows the step runs on state bytes made from it (one pass, one look at its verdict) and
+    agrees with the float route to rounding; evidence of another kind is taken as before, bit for bit, and
+    the look is not repeated for a while."""
+    from bayesiannetwork_amd.inference_machines.evidence import Evidence, HardEvidence
+    from bayesiannetwork_amd.inference_machines.hip_spa import HipSpaInferenceMachine, SpaInferenceMachineSettings
+    from bayesiannetwork_amd.optimizers.em_step import FlatModel
+
+    n = 32770
+    ts, network, ys = _leaf_model("c3a", "float32", "cuda")
+    gen = torch.Generator().manual_seed(21)
+    states = (torch.rand((len(ys), n), generator=gen) < 0.25).to(torch.uint8)
+    x = states.to(ts.dtype).cuda() * 0.999999 + 5e-7
+    stacked = torch.stack([1 - x, x], dim=2).contiguous()  # rows (1 - 5e-7, 5e-7) and (1 - 0.9999995, 0.9999995): four values
+    two_valued = Evidence(list(stacked.unbind(0)), ts)
+    settings = SpaInferenceMachineSettings(ts, True)
+    model = FlatModel.of(network)
+    model.assign(model.gather())
+
+    def machine_for(compaction):
+        machine = HipSpaInferenceMachine(settings, network, ys, n)
+        machine.enable_star_step(False)
+        machine.enable_evidence_compaction(compaction)
+        return machine
+
+    plain = machine_for(False)
+    ll_f, counts_f = plain.em_step_statistics(two_valued)
+    assert plain.evidence_compactions() == 0
+    compacting = machine_for(True)
+    ll_c, counts_c = compacting.em_step_statistics(two_valued)
+    assert compacting.evidence_compactions() == 1
+    assert abs(ll_c.item() - ll_f.item()) <= 2e-6 * abs(ll_f.item())
+    np.testing.assert_allclose(counts_c.cpu().numpy(), counts_f.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    # the whole step, and the same machine again on the next batch
+    ll_a, new_a = machine_for(False).em_step(two_valued, 0.2, 0.01)
+    new_a = new_a.clone()
+    model.assign(model.gather())
+    ll_b, new_b = compacting.em_step(two_valued, 0.2, 0.01)
+    assert compacting.evidence_compactions() == 2
+    assert abs(ll_b.item() - ll_a.item()) <= 2e-6 * abs(ll_a.item())
+    np.testing.assert_allclose(new_b.cpu().numpy(), new_a.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    model.assign(model.gather())
+
+    # one row of another kind anywhere: the float route, bit for bit
+    soft = stacked.clone()
+    soft[700, n - 3] = torch.tensor([0.25, 0.75], dtype=soft.dtype, device=soft.device)
+    soft_evidence = Evidence(list(soft.unbind(0)), ts)
+    ll_p, counts_p = machine_for(False).em_step_statistics(soft_evidence)
+    looking = machine_for(True)
+    ll_q, counts_q = looking.em_step_statistics(soft_evidence)
+    assert looking.evidence_compactions() == 0
+    assert ll_q.item() == ll_p.item() and torch.equal(counts_q, counts_p)
+    # ... and the next batches are taken as they come for a while, whatever they are
+    ll_r, counts_r = looking.em_step_statistics(two_valued)
+    assert looking.evidence_compactions() == 0
+    assert ll_r.item() == ll_f.item() and torch.equal(counts_r, counts_f)
+
+
 @pytest.mark.parametrize("iterations", [1, 2, 3, 4, 5, 6])
 def test_state_bytes_step_at_iteration_counts_around_the_diameter(iterations):
     """The launches of a step on state bytes depend on the number of iterations: the reduce launch
