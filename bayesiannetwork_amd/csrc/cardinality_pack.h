@@ -17,6 +17,11 @@
 namespace bn {
 
 constexpr int32_t kPackAbi = 3;  // bumped whenever a kernel's arguments or this table change
+// What a pack reports as its `abi`, and what the library expects of one: the number above together with the
+// sizes of the structures its kernels take as arguments (a pack left over from a build with other structures
+// would read its arguments wrongly: it is refused and the plan goes without it).  Defined where those structures
+// are known (dispatch_leaf.h: pack_abi_of_build); the library's value reaches the loader through this function.
+int32_t expected_pack_abi();
 
 struct LeafLoopRef {
   const void* fn;

@@ -121,6 +121,11 @@ inline LeafFamilyFn<T> leaf_family_lookup(int32_t d0, int32_t s) {
   return nullptr;
 }
 
+// the `abi` of a pack built from these headers (cardinality_pack.h)
+constexpr int32_t pack_abi_of_build() {
+  return kPackAbi + 1000 * (int32_t)(sizeof(LeafFamilyArgs<float>) + sizeof(LeafFamilyArgs<double>) + sizeof(WideArgs));
+}
+
 // two-parent families: the kernel of a (D0, D1, S) shape, nullptr for a shape without one
 template <typename T, int MODE>
 inline LeafFamilyFn<T> leaf_family_p2_lookup(int32_t d0, int32_t d1, int32_t s) {

@@ -7,4 +7,6 @@ template int launch_leaf_family<float>(Plan&, FactorGroup&, FusedFamily&, WideNo
                                      int32_t, int32_t, hipStream_t, bool, int32_t);
 
 bool hard_family_possible(const Plan& p, const FactorGroup& g, const FusedFamily& fam) { return hard_family_fits(p, g, fam); }
+
+int32_t expected_pack_abi() { return pack_abi_of_build(); }
 }  // namespace bn

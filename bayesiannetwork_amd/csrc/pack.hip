@@ -71,7 +71,7 @@ WideKernelRefs pack_wide(int32_t dtype) { return dtype == 0 ? wide_kernels_for<f
 }  // namespace bn
 
 extern "C" const bn::CardinalityPack* bn_cardinality_pack() {
-  static const bn::CardinalityPack pack = {bn::kPackAbi,        BN_PACK_D0,    bn::pack_family, bn::pack_family_pairs4,
+  static const bn::CardinalityPack pack = {bn::pack_abi_of_build(),        BN_PACK_D0,    bn::pack_family, bn::pack_family_pairs4,
                                            bn::pack_loop,       bn::pack_hard, bn::pack_wide};
   return &pack;
 }

@@ -30,6 +30,6 @@ const void* pack_p2(int32_t dtype, int32_t mode) { return dtype == 0 ? p2_of<flo
 }  // namespace bn
 
 extern "C" const bn::ShapePack* bn_shape_pack() {
-  static const bn::ShapePack pack = {bn::kPackAbi, BN_PACK2_D0, BN_PACK2_D1, BN_PACK2_S, bn::pack_p2};
+  static const bn::ShapePack pack = {bn::pack_abi_of_build(), BN_PACK2_D0, BN_PACK2_D1, BN_PACK2_S, bn::pack_p2};
   return &pack;
 }

@@ -28,7 +28,7 @@ const CardinalityPack* load_pack(int32_t d0) {
   using Entry = const CardinalityPack* (*)();
   Entry entry = reinterpret_cast<Entry>(dlsym(handle, "bn_cardinality_pack"));
   const CardinalityPack* pack = entry ? entry() : nullptr;
-  if (!pack || pack->abi != kPackAbi || pack->d0 != d0) {
+  if (!pack || pack->abi != expected_pack_abi() || pack->d0 != d0) {
     dlclose(handle);  // built for another version of the library
     return nullptr;
   }
@@ -44,7 +44,7 @@ const ShapePack* load_shape_pack(int32_t d0, int32_t d1, int32_t s) {
   using Entry = const ShapePack* (*)();
   Entry entry = reinterpret_cast<Entry>(dlsym(handle, "bn_shape_pack"));
   const ShapePack* pack = entry ? entry() : nullptr;
-  if (!pack || pack->abi != kPackAbi || pack->d0 != d0 || pack->d1 != d1 || pack->s != s) {
+  if (!pack || pack->abi != expected_pack_abi() || pack->d0 != d0 || pack->d1 != d1 || pack->s != s) {
     dlclose(handle);
     return nullptr;
   }
