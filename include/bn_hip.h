@@ -145,13 +145,13 @@ int64_t bn_plan_star_step_failures(const bn_plan* plan);
 /*
  * Float evidence that is hard evidence in disguise.  bn_em_step / bn_em_step_statistics look at float
  * evidence of batches of 32 768 observations and more before they start (float32 plans whose observed
- * nodes are all two-state leaves, evidence arrays at equal distances): when every row is (a, b) or
- * (b, a) for one pair of values - what the reference's one-hot evidence and its clamped variants are
- * (spa_v3/spa_inference_machine.py:115-117 enters whatever rows it is given) - the step runs on one
- * state byte per leaf and observation, as if states_dev had been given with on_value = max(a, b),
- * off_value = min(a, b): one pass over the evidence writes the bytes, the host reads its verdict
- * (one stream synchronisation inside the call), and every launch then reads an eighth of the bytes
- * it would have read.  Results agree with the float route to rounding (2e-6 relative), not bit for
+ * nodes are all two-state leaves, evidence arrays at equal distances): when the rows of all leaves and
+ * observations are two rows only, one whose first entry is the larger and one whose second is - what
+ * the reference's one-hot evidence and its clamped variants are (spa_v3/spa_inference_machine.py:115-117
+ * enters whatever rows it is given) - the step runs on one state byte per leaf and observation, the
+ * two states standing for those two rows: one pass over the evidence writes the bytes, the host reads
+ * its verdict (one stream synchronisation inside the call), and every launch then reads an eighth of
+ * the bytes it would have read.  Results agree with the float route to rounding (2e-6 relative), not bit for
  * bit.  Evidence of another kind is taken as before (and the next 63 calls do not look).  On by
  * default; bn_plan_enable_evidence_compaction(plan, 0) or BN_NO_EVIDENCE_COMPACTION=1 in the
  * environment switch it off; bn_plan_evidence_compactions counts the calls that ran this way.
