@@ -78,6 +78,14 @@ struct bn_plan {
   void* compact_verdict_host = nullptr;  // pinned: where the verdict is copied for the host to read
   int32_t compact_skip = 0;           // calls to go before evidence that was not of that kind is looked at again
   float compact_rows[6] = {};         // what the state bytes of the last compaction stand for (HardEvidenceRows)
+  // The batch after one of that kind is taken to be of that kind, with the same two rows: its step is enqueued
+  // on that guess while the pass over its evidence runs, and the verdict is read when everything is enqueued
+  // (no wait with an idle GPU).  A wrong guess - the parameters put back, the step run again - costs a step.
+  bool compact_have_rows = false;     // compact_rows are the last looked-at batch's
+  bool compact_guessing = false;      // the call at work runs on a guess
+  int32_t compact_blocks = 0;         // verdicts of the pass at work
+  hipEvent_t compact_event = nullptr; // the verdicts of the pass at work have reached the host
+  void* compact_cpts_backup = nullptr;  // the parameters before a step that runs on a guess
   int64_t compactions = 0;            // whole-step calls that ran on state bytes made this way
 };
 
@@ -1364,6 +1372,8 @@ int bn_plan_destroy(bn_plan* plan) {
   if (plan->finish_counter) (void)hipFree(plan->finish_counter);
   if (plan->compact_states) (void)hipFree(plan->compact_states);
   if (plan->compact_verdict_host) (void)hipHostFree(plan->compact_verdict_host);
+  if (plan->compact_event) (void)hipEventDestroy(plan->compact_event);
+  if (plan->compact_cpts_backup) (void)hipFree(plan->compact_cpts_backup);
   bn::release_fast(plan->p);
   release(plan->p);
   (void)hipSetDevice(prev);
@@ -1870,9 +1880,43 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
 // state bytes (plan->compact_rows: what they stand for), or null when the evidence is not of that kind
 // (or the step would not run on them).
 constexpr int64_t kCompactMinN = 32768;
+// What the blocks of the pass over the evidence have seen, once their verdicts are on the host: are the rows two
+// rows only, and which (rows: HardEvidenceRows)?
+bool compact_verdict_rows(const bn_plan* plan, int32_t blocks, float* rows) {
+  const bn::CompactVerdict* host = static_cast<const bn::CompactVerdict*>(plan->compact_verdict_host);
+  bn::CompactVerdict seen{};
+  for (int32_t i = 0; i < 4; ++i) seen.lo[i] = 0x7f800000u;
+  for (int32_t b = 0; b < blocks; ++b) {
+    seen.other |= host[b].other;
+    for (int32_t i = 0; i < 4; ++i) {
+      seen.lo[i] = std::min(seen.lo[i], host[b].lo[i]);
+      seen.hi[i] = std::max(seen.hi[i], host[b].hi[i]);
+    }
+  }
+  bool two_rows = seen.other == 0;
+  for (int32_t i = 0; i < 4; ++i) two_rows = two_rows && (seen.lo[i] == seen.hi[i] || seen.lo[i] > seen.hi[i]);
+  const bool has0 = seen.lo[0] <= seen.hi[0], has1 = seen.lo[2] <= seen.hi[2];
+  if (!two_rows || (!has0 && !has1)) return false;
+  // the rows of the two states (a state no observation has takes the other's: nothing reads it), and for a
+  // state byte beyond them - there is none - the smaller entries
+  auto value = [](uint32_t bits) {
+    float x;
+    std::memcpy(&x, &bits, sizeof x);
+    return x;
+  };
+  for (int32_t st = 0; st < 2; ++st) {
+    const int32_t from = (st == 0 ? has0 : has1) ? st : 1 - st;
+    rows[2 * st] = value(seen.lo[2 * from]);
+    rows[2 * st + 1] = value(seen.lo[2 * from + 1]);
+  }
+  rows[4] = rows[5] = std::min(std::min(rows[0], rows[1]), std::min(rows[2], rows[3]));
+  return true;
+}
+
 int compact_evidence(bn_plan* plan, const void* const* evidence_dev, int32_t num_iterations, hipStream_t s,
-                     const uint8_t** states) {
+                     const uint8_t** states, bool may_guess) {
   *states = nullptr;
+  plan->compact_guessing = false;
   bn::Plan& p = plan->p;
   static const bool off = getenv("BN_NO_EVIDENCE_COMPACTION") != nullptr;
   static const int64_t min_n = getenv("BN_COMPACT_MIN_N") ? atoll(getenv("BN_COMPACT_MIN_N")) : kCompactMinN;
@@ -1915,40 +1959,40 @@ int compact_evidence(bn_plan* plan, const void* const* evidence_dev, int32_t num
   BN_LAUNCH_CHECK("evidence_two_rows");
   prof_end(s);
   BN_HIP_CHECK(hipMemcpyAsync(host, verdict, (size_t)blocks * sizeof(bn::CompactVerdict), hipMemcpyDeviceToHost, s));
-  BN_HIP_CHECK(hipStreamSynchronize(s));
-  bn::CompactVerdict seen{};
-  for (int32_t i = 0; i < 4; ++i) seen.lo[i] = 0x7f800000u;
-  for (int32_t b = 0; b < blocks; ++b) {
-    seen.other |= host[b].other;
-    for (int32_t i = 0; i < 4; ++i) {
-      seen.lo[i] = std::min(seen.lo[i], host[b].lo[i]);
-      seen.hi[i] = std::max(seen.hi[i], host[b].hi[i]);
-    }
+  if (may_guess && plan->compact_have_rows) {
+    // of the same kind as the last batch, with the same rows - to be confirmed by settle_guess
+    if (!plan->compact_event) BN_HIP_CHECK(hipEventCreateWithFlags(&plan->compact_event, hipEventDisableTiming));
+    BN_HIP_CHECK(hipEventRecord(plan->compact_event, s));
+    plan->compact_guessing = true;
+    plan->compact_blocks = blocks;
+    *states = plan->compact_states;
+    ++plan->compactions;
+    return BN_OK;
   }
-  bool two_rows = seen.other == 0;
-  for (int32_t i = 0; i < 4; ++i) two_rows = two_rows && (seen.lo[i] == seen.hi[i] || seen.lo[i] > seen.hi[i]);
-  if (!two_rows) {
+  BN_HIP_CHECK(hipStreamSynchronize(s));
+  plan->compact_have_rows = compact_verdict_rows(plan, blocks, plan->compact_rows);
+  if (!plan->compact_have_rows) {
     plan->compact_skip = 63;  // evidence of another kind: the next batches are taken as they come
     return BN_OK;
   }
-  // the rows of the two states (a state no observation has takes the other's: nothing reads it), and for a
-  // state byte beyond them - there is none - the smaller entries
-  auto value = [](uint32_t bits) {
-    float x;
-    std::memcpy(&x, &bits, sizeof x);
-    return x;
-  };
-  const bool has0 = seen.lo[0] <= seen.hi[0], has1 = seen.lo[2] <= seen.hi[2];
-  if (!has0 && !has1) return BN_OK;
-  float* rows = plan->compact_rows;
-  for (int32_t st = 0; st < 2; ++st) {
-    const int32_t from = (st == 0 ? has0 : has1) ? st : 1 - st;
-    rows[2 * st] = value(seen.lo[2 * from]);
-    rows[2 * st + 1] = value(seen.lo[2 * from + 1]);
-  }
-  rows[4] = rows[5] = std::min(std::min(rows[0], rows[1]), std::min(rows[2], rows[3]));
   *states = plan->compact_states;
   ++plan->compactions;
+  return BN_OK;
+}
+
+// The end of a call that ran on a guess (compact_evidence): did the guess hold?
+int settle_guess(bn_plan* plan, bool* held) {
+  *held = true;
+  if (!plan->compact_guessing) return BN_OK;
+  plan->compact_guessing = false;
+  BN_HIP_CHECK(hipEventSynchronize(plan->compact_event));
+  float rows[6];
+  const bool two_rows = compact_verdict_rows(plan, plan->compact_blocks, rows);
+  if (two_rows && std::memcmp(rows, plan->compact_rows, sizeof rows) == 0) return BN_OK;
+  *held = false;
+  plan->compact_have_rows = false;
+  --plan->compactions;
+  if (!two_rows) plan->compact_skip = 63;
   return BN_OK;
 }
 
@@ -2049,8 +2093,14 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
   }
   const uint8_t* compacted = nullptr;  // state bytes made from float evidence (they stand for plan->compact_rows)
   if (!states_dev) {
-    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted)) return rc;
+    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted, true)) return rc;
     states_dev = compacted;
+  }
+  if (plan->compact_guessing) {
+    // the parameters as they are, should the guess turn out wrong
+    const size_t bytes = (size_t)p.cpt_total * p.elem_size;
+    if (!plan->compact_cpts_backup) BN_HIP_CHECK(hipMalloc(&plan->compact_cpts_backup, std::max<size_t>(bytes, 1)));
+    BN_HIP_CHECK(hipMemcpyAsync(plan->compact_cpts_backup, p.cpts, bytes, hipMemcpyDeviceToDevice, s));
   }
   if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream,
                              compacted ? plan->compact_rows : nullptr))
@@ -2124,6 +2174,15 @@ int bn_em_step(bn_plan* plan, const void* const* evidence_dev, const uint8_t* st
     BN_LAUNCH_CHECK("sum_partials");
     prof_end(s);
   }
+  bool held = true;
+  if (int rc2 = settle_guess(plan, &held)) return rc2;
+  if (!held) {
+    // the batch was not what it was taken for: the parameters as before, and the step again as the batch is
+    BN_HIP_CHECK(hipMemcpyAsync(p.cpts, plan->compact_cpts_backup, (size_t)p.cpt_total * p.elem_size, hipMemcpyDeviceToDevice, s));
+    bn::cpts_changed_fast(p);
+    return bn_em_step(plan, evidence_dev, nullptr, on_value, off_value, num_iterations, average, learning_rate, regularization,
+                      ll_out_dev, new_cpts_dev, stream);
+  }
   return BN_OK;
 }
 
@@ -2146,7 +2205,7 @@ int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const 
   plan->graphs_off = true;
   const uint8_t* compacted = nullptr;  // state bytes made from float evidence (they stand for plan->compact_rows)
   if (!states_dev) {
-    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted)) return rc;
+    if (int rc = compact_evidence(plan, evidence_dev, num_iterations, s, &compacted, true)) return rc;
     states_dev = compacted;
   }
   if (int rc = step_evidence(plan, evidence_dev, states_dev, on_value, off_value, num_iterations, stream,
@@ -2176,13 +2235,20 @@ int bn_em_step_statistics(bn_plan* plan, const void* const* evidence_dev, const 
   bn::set_evidence_in_caller(p, false);
   bn::set_states_in_caller(p, false);
   if (rc != BN_OK) return rc;
-  if (finished) return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
-  prof_begin("log_likelihood", (double)p.N * 8.0, s);
-  bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, ll_scale, ll_out_dev);
-  BN_LAUNCH_CHECK("sum_partials");
-  prof_end(s);
+  if (!finished) {
+    prof_begin("log_likelihood", (double)p.N * 8.0, s);
+    bn::launch(bn::sum_partials, dim3(1), dim3(256), 0, s, p.scratch, ll_blocks, ll_scale, ll_out_dev);
+    BN_LAUNCH_CHECK("sum_partials");
+    prof_end(s);
+  }
   // nobody will query this batch's messages: the plan is as after bn_reset_messages
-  return p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s);
+  if (int rc2 = p.dtype == BN_F32 ? reset_messages_t<float>(p, s) : reset_messages_t<double>(p, s)) return rc2;
+  bool held = true;
+  if (int rc2 = settle_guess(plan, &held)) return rc2;
+  if (!held)  // the batch was not what it was taken for: the sums again as the batch is
+    return bn_em_step_statistics(plan, evidence_dev, nullptr, on_value, off_value, num_iterations, average, ll_out_dev, accum_dev,
+                                 stream);
+  return BN_OK;
 }
 
 int bn_m_step(bn_plan* plan, const double* count_sums_dev, const void* old_cpts_dev, double learning_rate,

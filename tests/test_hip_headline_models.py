@@ -608,6 +608,41 @@ def test_float_evidence_that_is_hard_evidence_runs_on_state_bytes():
     assert looking.evidence_compactions() == 0
     assert ll_r.item() == ll_f.item() and torch.equal(counts_r, counts_f)
 
+    # The batch after one of that kind runs on the guess that it is of that kind too (the verdict of the pass
+    # over it is read when the step is enqueued): the same batch again - the guess holds, the same results;
+    guessing = machine_for(True)
+    ll_1, counts_1 = guessing.em_step_statistics(two_valued)
+    ll_2, counts_2 = guessing.em_step_statistics(two_valued)
+    assert guessing.evidence_compactions() == 2
+    assert ll_2.item() == ll_1.item() and torch.equal(counts_2, counts_1)
+    # ... a batch of another kind - the guess is wrong, the sums are formed again on the float arrays;
+    ll_3, counts_3 = guessing.em_step_statistics(soft_evidence)
+    assert guessing.evidence_compactions() == 2
+    assert ll_3.item() == ll_p.item() and torch.equal(counts_3, counts_p)
+    # ... and in a whole step the parameters are put back before it runs again: as if nothing had been guessed
+    guessed, straight = machine_for(True), machine_for(True)
+    for machine in (guessed, straight):
+        ll_g1, new_g1 = machine.em_step(two_valued, 0.2, 0.01)
+        model.assign(model.gather())
+    straight.enable_evidence_compaction(False)
+    ll_s, new_s = straight.em_step(soft_evidence, 0.2, 0.01)
+    new_s = new_s.clone()
+    model.assign(model.gather())
+    ll_g, new_g = guessed.em_step(soft_evidence, 0.2, 0.01)
+    assert guessed.evidence_compactions() == 1
+    assert ll_g.item() == ll_s.item() and torch.equal(new_g, new_s)
+    model.assign(model.gather())
+    # other rows of the same kind: the guess is wrong as well, the step runs again on the right ones
+    other_rows = Evidence(list(torch.stack([1 - (states.to(ts.dtype).cuda() * 0.99 + 0.005), states.to(ts.dtype).cuda() * 0.99 + 0.005],
+                                           dim=2).contiguous().unbind(0)), ts)
+    ll_o, counts_o = machine_for(False).em_step_statistics(other_rows)
+    switching = machine_for(True)
+    switching.em_step_statistics(two_valued)
+    ll_w, counts_w = switching.em_step_statistics(other_rows)
+    assert switching.evidence_compactions() == 2
+    assert abs(ll_w.item() - ll_o.item()) <= 2e-6 * abs(ll_o.item())
+    np.testing.assert_allclose(counts_w.cpu().numpy(), counts_o.cpu().numpy(), rtol=2e-6, atol=2e-6)
+
 
 @pytest.mark.parametrize("iterations", [1, 2, 3, 4, 5, 6])
 def test_state_bytes_step_at_iteration_counts_around_the_diameter(iterations):
