@@ -150,8 +150,11 @@ int64_t bn_plan_star_step_failures(const bn_plan* plan);
  * the reference's one-hot evidence and its clamped variants are (spa_v3/spa_inference_machine.py:115-117
  * enters whatever rows it is given) - the step runs on one state byte per leaf and observation, the
  * two states standing for those two rows: one pass over the evidence writes the bytes, the host reads
- * its verdict (one stream synchronisation inside the call), and every launch then reads an eighth of
- * the bytes it would have read.  Results agree with the float route to rounding (2e-6 relative), not bit for
+ * its verdict, and every launch then reads an eighth of the bytes it would have read.  The first such
+ * batch of a plan costs a stream synchronisation inside the call; the batch after one of that kind is
+ * taken to be of that kind too (same rows): its step is enqueued on that guess and the verdict is read
+ * when everything is enqueued - if the guess was wrong the parameters are put back and the step runs
+ * again, with the results of a call that never guessed.  Results agree with the float route to rounding (2e-6 relative), not bit for
  * bit.  Evidence of another kind is taken as before (and the next 63 calls do not look).  On by
  * default; bn_plan_enable_evidence_compaction(plan, 0) or BN_NO_EVIDENCE_COMPACTION=1 in the
  * environment switch it off; bn_plan_evidence_compactions counts the calls that ran this way.
