@@ -1879,7 +1879,7 @@ int bn_em_statistics_from_states(bn_plan* plan, const uint8_t* states_dev, doubl
 // passes over the float arrays it saves from batches of kCompactMinN observations on.  *states: the
 // state bytes (plan->compact_rows: what they stand for), or null when the evidence is not of that kind
 // (or the step would not run on them).
-constexpr int64_t kCompactMinN = 32768;
+constexpr int64_t kCompactMinN = 28672;
 // What the blocks of the pass over the evidence have seen, once their verdicts are on the host: are the rows two
 // rows only, and which (rows: HardEvidenceRows)?
 bool compact_verdict_rows(const bn_plan* plan, int32_t blocks, float* rows) {

@@ -732,7 +732,7 @@ class HipSpaInferenceMachine(IInferenceMachine):
     def enable_evidence_compaction(self, enabled: bool = True) -> None:
         """``em_step`` / ``em_step_statistics`` on float evidence whose rows are two rows only -
         one-hot evidence and its clamped variants - run on one state byte per leaf and observation
-        from batches of 32 768 observations on (results agree with the float route to rounding);
+        from batches of 28 672 observations on (results agree with the float route to rounding);
         ``False`` makes the engine read the float arrays in every launch."""
         _native.check(self._lib.bn_plan_enable_evidence_compaction(self._plan, 1 if enabled else 0))
 

@@ -144,7 +144,7 @@ int64_t bn_plan_star_step_launches(const bn_plan* plan);
 int64_t bn_plan_star_step_failures(const bn_plan* plan);
 /*
  * Float evidence that is hard evidence in disguise.  bn_em_step / bn_em_step_statistics look at float
- * evidence of batches of 32 768 observations and more before they start (float32 plans whose observed
+ * evidence of batches of 28 672 observations and more before they start (float32 plans whose observed
  * nodes are all two-state leaves, evidence arrays at equal distances): when the rows of all leaves and
  * observations are two rows only, one whose first entry is the larger and one whose second is - what
  * the reference's one-hot evidence and its clamped variants are (spa_v3/spa_inference_machine.py:115-117
