@@ -264,8 +264,13 @@ static __global__ void __launch_bounds__(256) evidence_two_rows(const float* __r
   const int64_t total = leaves * quads_per_leaf;
   uint32_t lo[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u}, hi[4] = {0u, 0u, 0u, 0u};
   bool other = false;
-  for (int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x; item < total; item += (int64_t)gridDim.x * 256) {
-    const int64_t leaf = item / quads_per_leaf, n0 = (item - leaf * quads_per_leaf) * 4;
+  // (leaf, four observations) of the thread's items without a division per item: one here, additions from there
+  const int64_t step = (int64_t)gridDim.x * 256;
+  const int64_t step_leaves = step / quads_per_leaf, step_quads = step - step_leaves * quads_per_leaf;
+  int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t leaf = item / quads_per_leaf, quad = item - leaf * quads_per_leaf;
+  for (; item < total; item += step) {
+    const int64_t n0 = quad * 4;
     const float* rows = ev + leaf * leaf_stride + n0 * 2;
     const bool whole = n0 + 4 <= N;  // (else two observations are left: N is even)
     const float4 first = *reinterpret_cast<const float4*>(rows);
@@ -275,22 +280,29 @@ static __global__ void __launch_bounds__(256) evidence_two_rows(const float* __r
 #pragma unroll
     for (int32_t v = 0; v < 4; ++v) {
       other |= !(x[v] >= 0.f && y[v] >= 0.f);
-      const uint32_t state = x[v] > y[v] ? 0u : 1u;
-      packed |= state << (8 * v);
+      const bool zero = x[v] > y[v];
+      packed |= (zero ? 0u : 1u) << (8 * v);
       const uint32_t bx = __builtin_bit_cast(uint32_t, x[v]), by = __builtin_bit_cast(uint32_t, y[v]);
-#pragma unroll
-      for (int32_t st = 0; st < 2; ++st) {
-        const bool mine = state == (uint32_t)st;
-        lo[2 * st] = mine && bx < lo[2 * st] ? bx : lo[2 * st];
-        hi[2 * st] = mine && bx > hi[2 * st] ? bx : hi[2 * st];
-        lo[2 * st + 1] = mine && by < lo[2 * st + 1] ? by : lo[2 * st + 1];
-        hi[2 * st + 1] = mine && by > hi[2 * st + 1] ? by : hi[2 * st + 1];
-      }
+      // (a row of the other state leaves the extremes alone: it enters as the value they start from)
+      lo[0] = min(lo[0], zero ? bx : 0x7f800000u);
+      hi[0] = max(hi[0], zero ? bx : 0u);
+      lo[1] = min(lo[1], zero ? by : 0x7f800000u);
+      hi[1] = max(hi[1], zero ? by : 0u);
+      lo[2] = min(lo[2], zero ? 0x7f800000u : bx);
+      hi[2] = max(hi[2], zero ? 0u : bx);
+      lo[3] = min(lo[3], zero ? 0x7f800000u : by);
+      hi[3] = max(hi[3], zero ? 0u : by);
     }
     if (whole)
       *reinterpret_cast<uint32_t*>(states + leaf * N + n0) = packed;
     else
       *reinterpret_cast<uint16_t*>(states + leaf * N + n0) = (uint16_t)packed;
+    quad += step_quads;
+    leaf += step_leaves;
+    if (quad >= quads_per_leaf) {
+      quad -= quads_per_leaf;
+      ++leaf;
+    }
   }
   // the wave's extremes, then the block's: every block leaves a verdict of its own (atomics of a few thousand
   // waves on the same eight words took 1.5 ms)
